@@ -1,0 +1,269 @@
+/*
+ * igdsp.h — C ABI of the MI355X (gfx950) G.711 + level-meter hot path.
+ *
+ * This is the drop-in boundary for ONE path of piyanon108/iGate4xSoftphoneDSP:
+ * the per-20 ms-RTP-frame work done behind the pjmedia transport adapter
+ *   transport_rtp_cb  -> RoIP_ED137::setIncomingRTP(tp_adapter*)   (TransportAdapter.cpp:240-316, roip_ed137.cpp:6541-6587)
+ *   transport_send_rtp -> RoIP_ED137::setOutgoingRTP(tp_adapter*)  (TransportAdapter.cpp:635-874, roip_ed137.cpp:6500-6536)
+ * plus the G.711 decode/encode that pjmedia performs around those hooks
+ * (TransportAdapter.cpp:301; codec selection roip_ed137.cpp:3546-3574) and the
+ * level-meter contract of audiometer.cpp:30-31 / Functions.cpp:2126-2230.
+ *
+ * Plain C types only; usable from C99 and C++11 (the reference builds with
+ * CONFIG += c++11, iGate4xSoftphoneDSP.pro:2).  No torch / HIP types appear
+ * here: device buffers are `void*`-compatible raw pointers, streams are an
+ * opaque `void*` (a hipStream_t, or NULL for the context's own stream).
+ *
+ * Error convention follows the reference (pj_status_t, PJ_SUCCESS == 0,
+ * TransportAdapter.cpp:135-223): every entry returns int, 0 == success,
+ * negative == IGDSP_E*.  Nothing here throws or aborts the host.
+ */
+#ifndef IGDSP_H
+#define IGDSP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IGDSP_ABI_VERSION 1
+
+/* ---- error codes (0 == PJ_SUCCESS-style success) ------------------------- */
+#define IGDSP_OK          0
+#define IGDSP_EINVAL    (-22)  /* bad argument (NULL, size, alignment, unknown codec)   */
+#define IGDSP_ENOMEM    (-12)  /* host or device allocation failed                      */
+#define IGDSP_ENODEV    (-19)  /* no usable gfx950 device / HIP runtime error            */
+#define IGDSP_ENOENT     (-2)  /* call_id not mapped to a channel (a4 routing miss)      */
+#define IGDSP_ERANGE    (-34)  /* channel / frame index out of the context's capacity    */
+#define IGDSP_EBUSY     (-16)  /* staging slot already holds an unflushed frame          */
+#define IGDSP_EDEVICE   (-5)   /* kernel launch / runtime failure (see igdsp_last_error) */
+
+/* ---- codec ids: RTP payload types, as gated at TransportAdapter.cpp:252 ---
+ * (WAVE_FORMAT_MULAW 0x0007 / WAVE_FORMAT_ALAW 0x0006 of Codecs.h:33-34 are the
+ * container tags; on the wire and in this ABI the RTP PT is the codec id.) */
+#define IGDSP_PT_PCMU      0   /* G.711 mu-law */
+#define IGDSP_PT_PCMA      8   /* G.711 A-law  */
+#define IGDSP_PT_R2S     123   /* ED-137 keep-alive: never metered (TransportAdapter.cpp:299,308) */
+
+/* ---- frame geometry (roip_ed137.h:112,115: CLOCK_RATE 8000, PTIME 20) ----- */
+#define IGDSP_CLOCK_RATE          8000
+#define IGDSP_PTIME_MS              20
+#define IGDSP_SAMPLES_PER_FRAME    160
+#define IGDSP_MAX_PAYLOAD          256   /* tp_adapter::payload_buff[256], TransportAdapter.h:66 */
+#define IGDSP_METER_FULL_SCALE   30000   /* audiometer.cpp:30-31 */
+
+/* ---- G.711 encoder variant -------------------------------------------------
+ * Decode is unique (ITU-T G.711 tables).  Two historic encoders exist; they
+ * agree on every value a decoder can produce and on ITU decision values, and
+ * differ only in rounding of some negative inputs / clipping:
+ *   SUN16 : 16-bit-domain Sun g711.c lineage (BIAS 0x84; A-law "-pcm-8" with
+ *           the <0 clamp) — the lineage pjmedia's alaw_ulaw.c carries.
+ *   G191  : 14/13-bit-domain ITU-T G.191 STL lineage (BIAS 0x21 after >>2;
+ *           A-law "-pcm-1" after >>3) — bit-identical to CPython `audioop`.
+ */
+#define IGDSP_ENC_SUN16   0
+#define IGDSP_ENC_G191    1
+
+/* ---- per-frame flags ------------------------------------------------------- */
+#define IGDSP_FLAG_SILENT   0x01  /* peak <= 8: digital silence (A 0xD5/0x55, mu 0xFF/0x7F/0xFE/0x7E) */
+#define IGDSP_FLAG_PROBE_D5 0x02  /* payload[28]==payload[38]==payload[48]==0xD5: the reference's own
+                                     TX silence probe on packet bytes 40/50/60 behind a 12-byte RTP
+                                     header (TransportAdapter.cpp:657-673) */
+#define IGDSP_FLAG_CLIPPED  0x04  /* peak == codec full scale (32124 mu / 32256 A) */
+#define IGDSP_FLAG_EMPTY    0x08  /* zero-length frame (missing / keep-alive slot): all fields 0 */
+
+/* Per channel-frame result, 16 bytes, naturally aligned.
+ *  sumsq     : exact sum of x^2 over the decoded int16 samples of the frame
+ *  rms       : sqrtf((float)sumsq / n)                 (fp32; oracle is float64, rel tol 1e-5)
+ *  peak      : max |x|                                  (<= 32256)
+ *  byte_mean : (uint8_t)(sum of raw payload bytes / n)  — bit-exact restatement of the
+ *              reference's "audioLevel" (roip_ed137.cpp:6564-6568, unsigned-char target)
+ *  flags     : IGDSP_FLAG_*                                                          */
+typedef struct igdsp_frame_stats {
+    uint64_t sumsq;
+    float    rms;
+    uint16_t peak;
+    uint8_t  byte_mean;
+    uint8_t  flags;
+} igdsp_frame_stats;
+
+/* Per-channel running aggregate / peak-hold, 32 bytes.  Mirrors the PTT-window
+ * logger (keeplogAudioLevel Functions.cpp:2126-2145; reset createPTTEventDataLogger
+ * Functions.cpp:2155-2167): while a channel's window is open each frame does
+ * count++, level_sum += byte_mean, level_max/min update, plus (new) sumsq_acc and
+ * peak_hold for the decoded-domain meter.  Reset state: all 0, level_min = 255. */
+typedef struct igdsp_chan_hold {
+    uint64_t sumsq_acc;   /* sum of frame sumsq over the window                       */
+    uint32_t count;       /* frames accumulated (trx::level_in_count)                 */
+    uint32_t level_sum;   /* exact sum of byte_mean; reference's uint16 OutgoingRTPSum
+                             (roip_ed137.h:741) equals (uint16_t)level_sum             */
+    uint32_t samples;     /* samples accumulated (count * n for full frames)          */
+    uint16_t peak_hold;   /* running max |x|                                          */
+    uint8_t  level_max;   /* trx::OutgoingRTPmax (init 0)                             */
+    uint8_t  level_min;   /* trx::OutgoingRTPmin (init 255)                           */
+    uint32_t n_silent;    /* frames flagged IGDSP_FLAG_SILENT                         */
+    uint32_t n_clipped;   /* frames flagged IGDSP_FLAG_CLIPPED                        */
+} igdsp_chan_hold;
+
+/* Node/launch aggregate: the packed vector of SURVEY 8(e).  All u64 so that ONE
+ * sum all-reduce (RCCL ncclSum over int64) yields sums AND the max: rank g writes
+ * its local peak only into peak_slot[g]; after the sum every rank holds all peaks. */
+#define IGDSP_AGG_MAX_RANKS 8
+typedef struct igdsp_aggregate {
+    uint64_t sumsq;                            /* sum of sumsq over all frames      */
+    uint64_t samples;                          /* samples metered                   */
+    uint64_t frames;                           /* non-empty frames metered          */
+    uint64_t n_silent;
+    uint64_t n_clipped;
+    uint64_t byte_mean_sum;                    /* sum of byte_mean (checksum-of-checksums) */
+    uint64_t peak_slot[IGDSP_AGG_MAX_RANKS];   /* this rank's peak in slot[rank]    */
+} igdsp_aggregate;
+#define IGDSP_AGG_WORDS (6 + IGDSP_AGG_MAX_RANKS)
+
+/* What igdsp_poll returns for one channel: everything host code needs to fill
+ * trx::IncomingRTP (roip_ed137.cpp:6570-6585) and feed updateInputLevel(int percent)
+ * (roip_ed137.cpp:584-592; scale audiometer.cpp:30-31). */
+typedef struct igdsp_level {
+    uint8_t  byte_mean;   /* -> trx->radioN->IncomingRTP / OutgoingRTP               */
+    uint8_t  flags;
+    uint16_t peak;
+    float    rms;
+    int32_t  percent;     /* int(float(rms*100.0/30000.0)), AudioMeter::onValueChanged */
+    uint16_t peak_hold;
+    uint16_t reserved;
+    uint32_t frames;      /* frames flushed for this channel since create            */
+} igdsp_level;
+
+typedef struct igdsp_ctx igdsp_ctx;
+
+/* ---- lifecycle -------------------------------------------------------------- */
+
+/* Create a context on HIP device `device` with staging capacity for
+ * `max_channels` concurrent calls.  Allocates the pinned host slab
+ * [max_channels][160], its device mirror, result buffers and a private stream.
+ * Fails with IGDSP_ENODEV when no gfx950 device/runtime is usable — there is
+ * no CPU fallback. */
+int igdsp_create(igdsp_ctx **out, int device, uint32_t max_channels);
+int igdsp_destroy(igdsp_ctx *ctx);
+/* Human-readable text of the last runtime error on this context ("" if none). */
+const char *igdsp_last_error(const igdsp_ctx *ctx);
+int igdsp_abi_version(void);
+/* Device the context is bound to; number of CUs (for grid sizing reports). */
+int igdsp_device_info(const igdsp_ctx *ctx, int *device, int *compute_units, char *name, size_t name_len);
+
+/* ---- a4: call-id -> channel routing (roip_ed137.cpp:6519-6534, 6570-6585) ---- */
+int igdsp_map_call(igdsp_ctx *ctx, int32_t call_id, uint32_t channel);
+int igdsp_unmap_call(igdsp_ctx *ctx, int32_t call_id);
+
+/* ---- (i) single-frame entry, callable from setIncomingRTP/setOutgoingRTP -------
+ * Inputs are exactly what those hooks read from tp_adapter: callID, payload
+ * pointer, payload length (roip_ed137.cpp:6549-6552) and the RTP PT
+ * (TransportAdapter.cpp:252).  Copies `payload` (borrowed; pjmedia owns pkt) into
+ * the channel's staging slot and returns; never blocks on the device.  Safe to
+ * call concurrently from several media threads for DIFFERENT channels; for one
+ * channel the last frame before a flush wins.  pt == 123 (R2S keep-alive) and
+ * unknown PTs are accepted and ignored (returns 0, nothing staged), like the
+ * reference which meters only pt != 123.  payloadlen > 256 -> IGDSP_EINVAL
+ * (the reference would overflow payload_buff[256] there, TransportAdapter.cpp:286). */
+int igdsp_on_rtp_frame(igdsp_ctx *ctx, int32_t call_id, uint8_t pt,
+                       const uint8_t *payload, uint32_t payloadlen);
+
+/* Upload every slot staged since the previous flush, run the decode+meter kernel
+ * over them, fold results into the per-channel hold state, and make them visible
+ * to igdsp_poll.  Called by ONE owner thread per context (e.g. a 20 ms timer).
+ * `n_frames_out` (optional) receives the number of staged frames processed. */
+int igdsp_flush(igdsp_ctx *ctx, uint32_t *n_frames_out);
+
+/* (iii) results poll for one channel (valid after a flush). */
+int igdsp_poll(igdsp_ctx *ctx, uint32_t channel, igdsp_level *out);
+int igdsp_poll_call(igdsp_ctx *ctx, int32_t call_id, igdsp_level *out);
+/* (iv) reset the peak-hold / window aggregate of one channel (PTT press,
+ * Functions.cpp:2155-2167). channel == UINT32_MAX resets all. */
+int igdsp_reset_hold(igdsp_ctx *ctx, uint32_t channel);
+/* Read back the hold state of one channel. */
+int igdsp_get_hold(igdsp_ctx *ctx, uint32_t channel, igdsp_chan_hold *out);
+
+/* ---- (ii) batched device entries ----------------------------------------------
+ * All d_* pointers are DEVICE pointers on the context's device.  Layout is
+ * time-major, as frames arrive: payload[f][c][n] u8, codec[c] u8 (RTP PT 0 / 8),
+ * stats[f][c], pcm[f][c][n] i16.  n = samples_per_frame (1..256; 160 is the tuned
+ * path).  d_len (optional, may be NULL) gives a per-frame valid length
+ * len[f][c] <= n for ragged input; bytes past len are ignored; len 0 marks an
+ * empty slot.  Work is enqueued on `stream` (a hipStream_t; NULL = the context's
+ * stream) and NOT synchronised. */
+
+/* a1+a3+a5+a7: decode + meter.  d_pcm may be NULL (meter-only, the headline).
+ * d_agg (optional) is an igdsp_aggregate on the device that this launch ADDS
+ * into (zero it first with igdsp_agg_reset); rank selects the peak slot. */
+int igdsp_decode_meter(igdsp_ctx *ctx,
+                       const uint8_t *d_payload, const uint8_t *d_codec, const uint16_t *d_len,
+                       uint32_t n_channels, uint32_t n_frames, uint32_t samples_per_frame,
+                       igdsp_frame_stats *d_stats, int16_t *d_pcm,
+                       igdsp_aggregate *d_agg, uint32_t rank, void *stream);
+
+/* a2: encode int16 PCM -> G.711 codes, per-channel law. variant = IGDSP_ENC_*. */
+int igdsp_encode(igdsp_ctx *ctx,
+                 const int16_t *d_pcm, const uint8_t *d_codec,
+                 uint32_t n_channels, uint32_t n_frames, uint32_t samples_per_frame,
+                 uint8_t *d_payload_out, int variant, void *stream);
+
+/* a1+a2+a5+a6 fused (config #5): decode -> stats -> re-encode -> per-channel hold.
+ * d_gate[c] (optional): 0 = window closed (frame metered but not folded into
+ * hold), non-zero = open.  d_hold[c] persists across launches. */
+int igdsp_roundtrip_peakhold(igdsp_ctx *ctx,
+                             const uint8_t *d_payload, const uint8_t *d_codec,
+                             uint32_t n_channels, uint32_t n_frames, uint32_t samples_per_frame,
+                             uint8_t *d_payload_out, igdsp_frame_stats *d_stats,
+                             igdsp_chan_hold *d_hold, const uint8_t *d_gate,
+                             int variant, void *stream);
+
+/* Fold stats[f][c] into hold[c] (for callers that ran igdsp_decode_meter). */
+int igdsp_hold_update(igdsp_ctx *ctx, const igdsp_frame_stats *d_stats,
+                      uint32_t n_channels, uint32_t n_frames, uint32_t samples_per_frame,
+                      igdsp_chan_hold *d_hold, const uint8_t *d_gate, void *stream);
+int igdsp_hold_reset(igdsp_ctx *ctx, igdsp_chan_hold *d_hold, uint32_t n_channels,
+                     const uint8_t *d_reset_mask, void *stream);
+
+int igdsp_agg_reset(igdsp_ctx *ctx, igdsp_aggregate *d_agg, void *stream);
+
+/* ---- synthetic input generators (device side; SURVEY 8(d) definitions) ---------
+ * D-uniform: byte k of global byte index g is
+ *   (splitmix64(seed + (g>>3)) >> (8*(g&7))) & 0xFF,  g = first_byte + k
+ * so any shard of the [F][C][n] array is reproducible on any GPU count. */
+int igdsp_gen_uniform(igdsp_ctx *ctx, uint8_t *d_out, uint64_t n_bytes,
+                      uint64_t seed, uint64_t first_byte, void *stream);
+
+/* ---- small device-memory helpers for hosts that do not carry a HIP runtime
+ * of their own (the Qt/C++ softphone).  Thin wrappers; all synchronous except
+ * where a stream is given. */
+int igdsp_dev_alloc(igdsp_ctx *ctx, void **d_ptr, size_t bytes);
+int igdsp_dev_free(igdsp_ctx *ctx, void *d_ptr);
+int igdsp_copy_h2d(igdsp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int igdsp_copy_d2h(igdsp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int igdsp_dev_memset(igdsp_ctx *ctx, void *d_ptr, int value, size_t bytes);
+int igdsp_sync(igdsp_ctx *ctx, void *stream);
+
+/* ---- measurement helpers (HIP events on the launch stream; bench.py uses these
+ * so timing does not depend on which stream torch considers current) ------------ */
+int igdsp_timer_create(igdsp_ctx *ctx, void **timer);
+int igdsp_timer_destroy(igdsp_ctx *ctx, void *timer);
+int igdsp_timer_start(igdsp_ctx *ctx, void *timer, void *stream);
+int igdsp_timer_stop(igdsp_ctx *ctx, void *timer, void *stream);
+int igdsp_timer_elapsed_ms(igdsp_ctx *ctx, void *timer, float *ms); /* syncs on stop */
+
+/* Read-only streaming-read calibration kernel (16 B/lane loads, xor-folded into
+ * one word per workgroup): the "measured read-stream" the roofline is quoted
+ * against besides the 8 TB/s nominal. */
+int igdsp_stream_read(igdsp_ctx *ctx, const void *d_src, size_t bytes, uint64_t *d_sink, void *stream);
+
+/* Kernel variant selection for experiments (0 = default tuned path).
+ *   1 = one wavefront per channel-frame (40 lanes x dword), the literal north_star mapping
+ *   2 = chunked: one wavefront per 32 consecutive frames, 16 B/lane loads (default for n == 160) */
+int igdsp_set_variant(igdsp_ctx *ctx, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IGDSP_H */
