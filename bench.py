@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Headline bench: Msamples/s of G.711 mu-law decode + RMS/peak/byte-mean meter,
+65 536 channels @ 8 kHz per GPU, F = 128 frames (20 ms each) per launch.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (igdsp_decode_meter through the C ABI) over one
+device-resident batch payload[F][C][160] (1.34 GB per GPU: larger than the 256 MB
+Infinity Cache, so the figure is an HBM figure).  Channels shard by contiguous range
+across ranks (weak scaling: 65 536 ch per GPU; N = 8 is BASELINE configs[3], 524 288 ch)
+with ONE 112-byte RCCL all-reduce per launch for the node-wide sum-of-squares / peak,
+issued on a side stream behind the kernel's event.
+
+Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events on the launch
+stream, `cpu_baseline` is the CPU oracle timed on this box's host cores (N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_SAMPLES = 160
+# algorithmic bytes per sample, meter-only = (160 payload + 1 codec id + 16 result) / 160
+BYTES_PER_SAMPLE = {"meter": (160 + 1 + 16) / 160.0, "store": (160 + 1 + 16 + 320) / 160.0}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--channels", type=int, default=65536, help="channels PER GPU")
+    ap.add_argument("--frames", type=int, default=128)
+    ap.add_argument("--mode", choices=["meter", "store"], default="meter")
+    ap.add_argument("--variant", type=int, default=0, help="0 tuned default, 1 wave-per-frame, 2 chunk32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--stream-calib", action="store_true", help="also time the read-only stream kernel")
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds: float):
+    """The oracle's table-decode + exact sum-of-squares + peak + sqrt loop, one frame
+    at a time, on a bounded sample of the SAME workload (first 4 096 ch x 32 frames of the D-uniform
+    stream), all host cores and single thread."""
+    import numpy as np
+
+    from oracle import oracle as orc   # checker/baseline only
+
+    C_, F_ = 4096, 32
+    payload = orc.gen_uniform(F_ * C_ * N_SAMPLES).reshape(F_, C_, N_SAMPLES)
+    codec = np.zeros((C_,), np.uint8)
+    samples = payload.size
+    cores = len(os.sched_getaffinity(0))
+    t1 = orc.time_decode_meter(payload, codec, 1, 1)
+    reps1 = max(1, int(0.25 * seconds / max(t1, 1e-6)))
+    t1 = orc.time_decode_meter(payload, codec, 1, reps1) / reps1
+    tn = orc.time_decode_meter(payload, codec, cores, 1)
+    repsn = max(1, int(0.6 * seconds / max(tn, 1e-6)))
+    tn = orc.time_decode_meter(payload, codec, cores, repsn) / repsn
+    tb = orc.time_byte_mean(payload, cores, max(1, repsn // 2)) / max(1, repsn // 2)
+    return {
+        "value": round(samples / tn / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "sample": f"oracle B1 (scalar table decode + u64 sum x^2 + peak + sqrt, -O2) on the first {C_} ch x {F_} frames "
+                  f"of the same D-uniform stream, x{repsn} passes, {cores} pthreads",
+        "single_thread_value": round(samples / t1 / 1e6, 2),
+        "reference_loop_byte_mean_value": round(samples / tb / 1e6, 2),
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from igate4xsoftphonedsp_amd import capi
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"WORLD_SIZE {world} != --gpus {args.gpus}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the igdsp kernels have no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world > capi.AGG_MAX_RANKS:
+        raise SystemExit("aggregate vector has 8 peak slots")
+
+    C_, F_, n = args.channels, args.frames, N_SAMPLES
+    C_total = C_ * world
+    ctx = capi.Context(device=local, max_channels=1024)
+    ctx.set_variant(args.variant)
+    main_s = torch.cuda.current_stream()
+    comm_s = torch.cuda.Stream()
+    hs = main_s.cuda_stream
+
+    # ---- synthetic input, generated on the device, shard-invariant: this rank holds
+    # channels [rank*C, (rank+1)*C) of the global [F][C_total][160] D-uniform array.
+    d_pl = torch.empty((F_, C_, n), dtype=torch.uint8, device="cuda")
+    for f in range(F_):
+        first = (f * C_total + rank * C_) * n
+        ctx.gen_uniform(d_pl[f], C_ * n, first_byte=first, stream=hs)
+    d_cd = torch.zeros((C_,), dtype=torch.uint8, device="cuda")           # mu-law (RTP PT 0) everywhere
+    d_st = torch.zeros((F_ * C_ * 2,), dtype=torch.int64, device="cuda")   # igdsp_frame_stats[F][C]
+    d_pcm = torch.empty((F_, C_, n), dtype=torch.int16, device="cuda") if args.mode == "store" else None
+    aggs = [torch.zeros((capi.AGG_WORDS,), dtype=torch.int64, device="cuda") for _ in range(2)]
+    ev_k = [torch.cuda.Event() for _ in range(2)]
+    ev_c = [torch.cuda.Event() for _ in range(2)]
+    timers = [ctx.timer() for _ in range(args.steps)]
+
+    def step(i: int, timer=None):
+        b = i & 1
+        main_s.wait_event(ev_c[b])                 # the all-reduce that last used this aggregate buffer is done
+        aggs[b].zero_()
+        if timer is not None:
+            timer.start(hs)
+        ctx.decode_meter(d_pl, d_cd, C_, F_, n, d_st, pcm=d_pcm, agg=aggs[b], rank=rank, stream=hs)
+        if timer is not None:
+            timer.stop(hs)
+        if world > 1:                              # node-wide sum / peak: one 112-byte all-reduce per launch, side stream
+            ev_k[b].record(main_s)
+            with torch.cuda.stream(comm_s):
+                comm_s.wait_event(ev_k[b])
+                dist.all_reduce(aggs[b], op=dist.ReduceOp.SUM)
+                ev_c[b].record(comm_s)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, timers[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kern_ms = [tm.elapsed_ms() for tm in timers]
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    kern_med_ms = sorted(kern_ms)[len(kern_ms) // 2]
+
+    # node-wide aggregate from the last launch (after the all-reduce every rank holds all peak slots)
+    last = aggs[(args.warmup + args.steps - 1) & 1].cpu().numpy().view(np.uint64)
+    node_rms = float(np.sqrt(float(last[0]) / max(float(last[1]), 1.0)))
+    node_peak = int(last[6:].max())
+
+    samples_per_step_rank = C_ * F_ * n
+    total_samples = samples_per_step_rank * world * args.steps
+    value = total_samples / dt / 1e6
+    bps = BYTES_PER_SAMPLE[args.mode]
+    achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9
+    kernel_name = "k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk32"
+
+    out = {
+        "metric": "Msamples/s G.711 decode+RMS, 65536ch@8kHz; %HBM roofline at 1/2/4/8 GPU",
+        "value": round(value, 1),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{C_} ch/GPU x {F_} frames x {n} samples mu-law decode+meter ({args.mode}), "
+                        f"device-resident {d_pl.numel() / 1e9:.2f} GB/GPU, D-uniform seed 0x20241218",
+            "channels_per_gpu": C_, "channels_total": C_total, "frames_per_launch": F_, "samples_per_frame": n,
+            "sharding": "contiguous channel ranges, no data-path collective; one 112 B all-reduce per launch" if world > 1 else "single GPU",
+            "kernel_variant": args.variant,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": kernel_name, "kernel_avg_ms": round(kern_avg_ms, 4), "kernel_median_ms": round(kern_med_ms, 4),
+            "algorithmic_bytes_per_sample": round(bps, 5),
+            "algorithmic_bytes_per_launch": int(samples_per_step_rank * bps),
+        },
+        "aggregate": {"node_rms": round(node_rms, 3), "node_peak": node_peak, "samples": int(last[1])},
+    }
+
+    if args.stream_calib:
+        sink = torch.zeros((1,), dtype=torch.int64, device="cuda")
+        tm = ctx.timer()
+        for _ in range(3):
+            ctx.stream_read(d_pl, d_pl.numel(), sink, stream=hs)
+        tm.start(hs)
+        for _ in range(10):
+            ctx.stream_read(d_pl, d_pl.numel(), sink, stream=hs)
+        tm.stop(hs)
+        out["roofline"]["stream_read_GBs"] = round(d_pl.numel() * 10 / (tm.elapsed_ms() * 1e-3) / 1e9, 1)
+
+    traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            with open(traffic_file) as fh:
+                tr = json.load(fh)
+            if tr.get("kernel") == kernel_name and tr.get("channels") == C_ and tr.get("frames") == F_ and tr.get("mode") == args.mode:
+                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = tr.get("source")
+        except Exception:
+            pass
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    for tm in timers:
+        tm.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

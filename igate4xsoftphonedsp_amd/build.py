@@ -1,0 +1,76 @@
+"""Builds ``libigdsp.so`` (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m igate4xsoftphonedsp_amd.build [--force] [--asm]
+
+hipcc cross-compiles without a GPU, so this also runs in the build container;
+the resulting .so travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB = os.path.join(PKG, "libigdsp.so")
+HOST_LIB = os.path.join(PKG, "libigdsp_host.so")
+
+DEVICE_SOURCES = ["igdsp_kernels.hip", "igdsp_capi.hip"]
+HOST_SOURCES = ["igdsp_host.cpp"]          # C++ mirror of the reference's adapter/hook interface
+HEADERS = ["igdsp_internal.h", os.path.join(INCLUDE, "igdsp.h")]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the gfx950 code objects cannot be built")
+
+
+def _stale(target: str, sources: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def build(force: bool = False, save_asm: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in DEVICE_SOURCES]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    if force or save_asm or _stale(LIB, deps):
+        cmd = [
+            _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+            "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-result",
+            "-o", LIB, *srcs,
+        ]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=PKG)
+        if save_asm:   # second pass next to a throw-away output: keeps the .s / resource remarks under _asm/
+            asm_dir = os.path.join(PKG, "_asm")
+            os.makedirs(asm_dir, exist_ok=True)
+            acmd = list(cmd)
+            acmd[acmd.index("-o") + 1] = os.path.join(asm_dir, "libigdsp_asm.so")
+            acmd[1:1] = ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+            subprocess.run(acmd, check=True, cwd=asm_dir)
+    host_srcs = [os.path.join(PKG, "host", s) for s in HOST_SOURCES]
+    if all(os.path.exists(s) for s in host_srcs):
+        hdeps = host_srcs + [os.path.join(PKG, "host", "igdsp_host.h"), os.path.join(INCLUDE, "igdsp.h")]
+        if force or _stale(HOST_LIB, hdeps + [LIB]):
+            cmd = [
+                "g++", "-O2", "-std=c++11", "-fPIC", "-shared", "-Wall", "-I", INCLUDE, "-I", os.path.join(PKG, "host"),
+                "-o", HOST_LIB, *host_srcs, "-L", PKG, "-ligdsp", "-Wl,-rpath,$ORIGIN", "-lpthread",
+            ]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True, cwd=PKG)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, save_asm="--asm" in sys.argv, verbose=True)
+    print("built", LIB)

@@ -1,0 +1,261 @@
+"""ctypes binding of ``include/igdsp.h`` (``libigdsp.so``).
+
+This is plumbing: it declares the C prototypes and turns negative return codes
+into ``IgdspError``.  Device buffers are passed as raw integer addresses
+(``tensor.data_ptr()``), streams as ``torch.cuda.current_stream().cuda_stream``.
+There is no fallback: if the HIP extension is missing or no gfx950 device is
+present, importing works but every use raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libigdsp.so")
+
+ABI_VERSION = 1
+PT_PCMU, PT_PCMA, PT_R2S = 0, 8, 123
+SAMPLES_PER_FRAME = 160
+MAX_PAYLOAD = 256
+ENC_SUN16, ENC_G191 = 0, 1
+FLAG_SILENT, FLAG_PROBE_D5, FLAG_CLIPPED, FLAG_EMPTY = 1, 2, 4, 8
+AGG_MAX_RANKS = 8
+AGG_WORDS = 6 + AGG_MAX_RANKS
+
+ERRORS = {
+    0: "IGDSP_OK", -22: "IGDSP_EINVAL", -12: "IGDSP_ENOMEM", -19: "IGDSP_ENODEV", -2: "IGDSP_ENOENT",
+    -34: "IGDSP_ERANGE", -16: "IGDSP_EBUSY", -5: "IGDSP_EDEVICE",
+}
+
+# numpy views of the ABI structs (layout asserted against the C side in tests)
+FRAME_STATS = np.dtype(
+    [("sumsq", "<u8"), ("rms", "<f4"), ("peak", "<u2"), ("byte_mean", "u1"), ("flags", "u1")], align=True
+)
+CHAN_HOLD = np.dtype(
+    [("sumsq_acc", "<u8"), ("count", "<u4"), ("level_sum", "<u4"), ("samples", "<u4"), ("peak_hold", "<u2"),
+     ("level_max", "u1"), ("level_min", "u1"), ("n_silent", "<u4"), ("n_clipped", "<u4")],
+    align=True,
+)
+AGGREGATE = np.dtype(
+    [("sumsq", "<u8"), ("samples", "<u8"), ("frames", "<u8"), ("n_silent", "<u8"), ("n_clipped", "<u8"),
+     ("byte_mean_sum", "<u8"), ("peak_slot", "<u8", (AGG_MAX_RANKS,))]
+)
+
+
+class Level(C.Structure):
+    _fields_ = [("byte_mean", C.c_uint8), ("flags", C.c_uint8), ("peak", C.c_uint16), ("rms", C.c_float),
+                ("percent", C.c_int32), ("peak_hold", C.c_uint16), ("reserved", C.c_uint16), ("frames", C.c_uint32)]
+
+
+class IgdspError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        self.code = code
+        super().__init__(f"{where} failed: {ERRORS.get(code, code)}" + (f" ({detail})" if detail else ""))
+
+
+# every symbol include/igdsp.h declares: (name, restype, argtypes)
+_vp, _u32, _u64, _i32, _int = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_int
+PROTOTYPES = [
+    ("igdsp_abi_version", _int, []),
+    ("igdsp_create", _int, [C.POINTER(_vp), _int, _u32]),
+    ("igdsp_destroy", _int, [_vp]),
+    ("igdsp_last_error", C.c_char_p, [_vp]),
+    ("igdsp_device_info", _int, [_vp, C.POINTER(_int), C.POINTER(_int), C.c_char_p, C.c_size_t]),
+    ("igdsp_map_call", _int, [_vp, _i32, _u32]),
+    ("igdsp_unmap_call", _int, [_vp, _i32]),
+    ("igdsp_on_rtp_frame", _int, [_vp, _i32, C.c_uint8, _vp, _u32]),
+    ("igdsp_flush", _int, [_vp, C.POINTER(_u32)]),
+    ("igdsp_poll", _int, [_vp, _u32, C.POINTER(Level)]),
+    ("igdsp_poll_call", _int, [_vp, _i32, C.POINTER(Level)]),
+    ("igdsp_reset_hold", _int, [_vp, _u32]),
+    ("igdsp_get_hold", _int, [_vp, _u32, _vp]),
+    ("igdsp_decode_meter", _int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
+    ("igdsp_encode", _int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _int, _vp]),
+    ("igdsp_roundtrip_peakhold", _int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _int, _vp]),
+    ("igdsp_hold_update", _int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    ("igdsp_hold_reset", _int, [_vp, _vp, _u32, _vp, _vp]),
+    ("igdsp_agg_reset", _int, [_vp, _vp, _vp]),
+    ("igdsp_gen_uniform", _int, [_vp, _vp, _u64, _u64, _u64, _vp]),
+    ("igdsp_dev_alloc", _int, [_vp, C.POINTER(_vp), C.c_size_t]),
+    ("igdsp_dev_free", _int, [_vp, _vp]),
+    ("igdsp_copy_h2d", _int, [_vp, _vp, _vp, C.c_size_t]),
+    ("igdsp_copy_d2h", _int, [_vp, _vp, _vp, C.c_size_t]),
+    ("igdsp_dev_memset", _int, [_vp, _vp, _int, C.c_size_t]),
+    ("igdsp_sync", _int, [_vp, _vp]),
+    ("igdsp_timer_create", _int, [_vp, C.POINTER(_vp)]),
+    ("igdsp_timer_destroy", _int, [_vp, _vp]),
+    ("igdsp_timer_start", _int, [_vp, _vp, _vp]),
+    ("igdsp_timer_stop", _int, [_vp, _vp, _vp]),
+    ("igdsp_timer_elapsed_ms", _int, [_vp, _vp, C.POINTER(C.c_float)]),
+    ("igdsp_stream_read", _int, [_vp, _vp, C.c_size_t, _vp, _vp]),
+    ("igdsp_set_variant", _int, [_vp, _int]),
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen libigdsp.so and bind every prototype.  Raises if the extension is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m igate4xsoftphonedsp_amd.build` "
+                "(there is no CPU fallback for the igdsp kernels)"
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in PROTOTYPES:
+            fn = getattr(L, name)          # AttributeError here == ABI symbol missing
+            fn.restype = res
+            fn.argtypes = args
+        if L.igdsp_abi_version() != ABI_VERSION:
+            raise ImportError(f"libigdsp ABI {L.igdsp_abi_version()} != binding {ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def _ptr(x) -> int | None:
+    """device pointer of a torch tensor / raw int / None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()
+
+
+class Context:
+    """RAII wrapper over ``igdsp_ctx``.  ``stream`` arguments are raw ``hipStream_t`` integers."""
+
+    def __init__(self, device: int = 0, max_channels: int = 4096):
+        self.L = load()
+        h = _vp()
+        rc = self.L.igdsp_create(C.byref(h), device, max_channels)
+        if rc != 0:
+            raise IgdspError(rc, "igdsp_create", "no usable gfx950 device" if rc == -19 else "")
+        self.h = h
+        self.max_channels = max_channels
+
+    # -- helpers
+    def _ck(self, rc: int, where: str):
+        if rc != 0:
+            raise IgdspError(rc, where, (self.L.igdsp_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.igdsp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def device_info(self):
+        dev, cus = _int(), _int()
+        name = C.create_string_buffer(128)
+        self._ck(self.L.igdsp_device_info(self.h, C.byref(dev), C.byref(cus), name, 128), "igdsp_device_info")
+        return {"device": dev.value, "compute_units": cus.value, "name": name.value.decode()}
+
+    def set_variant(self, v: int):
+        self._ck(self.L.igdsp_set_variant(self.h, v), "igdsp_set_variant")
+
+    # -- single-frame path (mirrors setIncomingRTP / setOutgoingRTP inputs)
+    def map_call(self, call_id: int, channel: int):
+        self._ck(self.L.igdsp_map_call(self.h, call_id, channel), "igdsp_map_call")
+
+    def unmap_call(self, call_id: int):
+        self._ck(self.L.igdsp_unmap_call(self.h, call_id), "igdsp_unmap_call")
+
+    def on_rtp_frame(self, call_id: int, pt: int, payload: bytes) -> int:
+        buf = (C.c_uint8 * len(payload)).from_buffer_copy(payload) if payload else None
+        return self.L.igdsp_on_rtp_frame(self.h, call_id, pt, C.cast(buf, _vp) if buf is not None else None, len(payload))
+
+    def flush(self) -> int:
+        n = _u32()
+        self._ck(self.L.igdsp_flush(self.h, C.byref(n)), "igdsp_flush")
+        return n.value
+
+    def poll(self, channel: int) -> Level:
+        lv = Level()
+        self._ck(self.L.igdsp_poll(self.h, channel, C.byref(lv)), "igdsp_poll")
+        return lv
+
+    def poll_call(self, call_id: int) -> Level:
+        lv = Level()
+        self._ck(self.L.igdsp_poll_call(self.h, call_id, C.byref(lv)), "igdsp_poll_call")
+        return lv
+
+    def reset_hold(self, channel: int = 0xFFFFFFFF):
+        self._ck(self.L.igdsp_reset_hold(self.h, channel), "igdsp_reset_hold")
+
+    def get_hold(self, channel: int) -> np.ndarray:
+        out = np.zeros((), dtype=CHAN_HOLD)
+        self._ck(self.L.igdsp_get_hold(self.h, channel, out.ctypes.data_as(_vp)), "igdsp_get_hold")
+        return out
+
+    # -- batched device entries
+    def decode_meter(self, payload, codec, C_, F_, n, stats, pcm=None, length=None, agg=None, rank=0, stream=None):
+        self._ck(self.L.igdsp_decode_meter(self.h, _ptr(payload), _ptr(codec), _ptr(length), C_, F_, n, _ptr(stats),
+                                           _ptr(pcm), _ptr(agg), rank, stream), "igdsp_decode_meter")
+
+    def encode(self, pcm, codec, C_, F_, n, out, variant=ENC_SUN16, stream=None):
+        self._ck(self.L.igdsp_encode(self.h, _ptr(pcm), _ptr(codec), C_, F_, n, _ptr(out), variant, stream), "igdsp_encode")
+
+    def roundtrip_peakhold(self, payload, codec, C_, F_, n, out, stats, hold, gate=None, variant=ENC_SUN16, stream=None):
+        self._ck(self.L.igdsp_roundtrip_peakhold(self.h, _ptr(payload), _ptr(codec), C_, F_, n, _ptr(out), _ptr(stats),
+                                                 _ptr(hold), _ptr(gate), variant, stream), "igdsp_roundtrip_peakhold")
+
+    def hold_update(self, stats, C_, F_, n, hold, gate=None, stream=None):
+        self._ck(self.L.igdsp_hold_update(self.h, _ptr(stats), C_, F_, n, _ptr(hold), _ptr(gate), stream), "igdsp_hold_update")
+
+    def hold_reset(self, hold, C_, mask=None, stream=None):
+        self._ck(self.L.igdsp_hold_reset(self.h, _ptr(hold), C_, _ptr(mask), stream), "igdsp_hold_reset")
+
+    def agg_reset(self, agg, stream=None):
+        self._ck(self.L.igdsp_agg_reset(self.h, _ptr(agg), stream), "igdsp_agg_reset")
+
+    def gen_uniform(self, out, n_bytes, seed=0x20241218, first_byte=0, stream=None):
+        self._ck(self.L.igdsp_gen_uniform(self.h, _ptr(out), n_bytes, seed, first_byte, stream), "igdsp_gen_uniform")
+
+    def stream_read(self, src, n_bytes, sink, stream=None):
+        self._ck(self.L.igdsp_stream_read(self.h, _ptr(src), n_bytes, _ptr(sink), stream), "igdsp_stream_read")
+
+    def sync(self, stream=None):
+        self._ck(self.L.igdsp_sync(self.h, stream), "igdsp_sync")
+
+    # -- timers
+    def timer(self):
+        return Timer(self)
+
+
+class Timer:
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.t = _vp()
+        ctx._ck(ctx.L.igdsp_timer_create(ctx.h, C.byref(self.t)), "igdsp_timer_create")
+
+    def start(self, stream=None):
+        self.ctx._ck(self.ctx.L.igdsp_timer_start(self.ctx.h, self.t, stream), "igdsp_timer_start")
+
+    def stop(self, stream=None):
+        self.ctx._ck(self.ctx.L.igdsp_timer_stop(self.ctx.h, self.t, stream), "igdsp_timer_stop")
+
+    def elapsed_ms(self) -> float:
+        ms = C.c_float()
+        self.ctx._ck(self.ctx.L.igdsp_timer_elapsed_ms(self.ctx.h, self.t, C.byref(ms)), "igdsp_timer_elapsed_ms")
+        return ms.value
+
+    def close(self):
+        if self.t:
+            self.ctx.L.igdsp_timer_destroy(self.ctx.h, self.t)
+            self.t = None

@@ -1,0 +1,41 @@
+// Internal launcher declarations shared by igdsp_kernels.hip and igdsp_capi.hip.
+// Not part of the ABI (include/igdsp.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "igdsp.h"
+
+namespace igdsp {
+
+// Geometry of the tuned n == 160 path ("chunk32"): one wavefront owns 32
+// consecutive channel-frames = 5120 contiguous bytes = 5 wave-wide 16 B/lane loads.
+constexpr int kFrame = IGDSP_SAMPLES_PER_FRAME;        // 160 B
+constexpr int kChunkFrames = 32;
+constexpr int kChunkBytes = kChunkFrames * kFrame;     // 5120
+constexpr int kPiecesPerFrame = kFrame / 16;           // 10 x 16 B
+constexpr int kPiecesPerChunk = kChunkFrames * kPiecesPerFrame;  // 320
+constexpr int kLoadsPerChunk = kPiecesPerChunk / 64;   // 5
+constexpr int kWavesPerBlock = 16;                     // 1024 threads, one block per CU
+constexpr int kBlockThreads = kWavesPerBlock * 64;
+
+struct LaunchCfg {
+    int compute_units;   // persistent grid = compute_units blocks
+};
+
+hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant,
+                               const uint8_t *payload, const uint8_t *codec, const uint16_t *len,
+                               uint32_t C, uint32_t F, uint32_t n,
+                               igdsp_frame_stats *stats, int16_t *pcm,
+                               igdsp_aggregate *agg, uint32_t rank, hipStream_t s);
+hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t *codec,
+                         uint32_t C, uint32_t F, uint32_t n, uint8_t *out, int variant, hipStream_t s);
+hipError_t launch_roundtrip(const LaunchCfg &cfg, const uint8_t *payload, const uint8_t *codec,
+                            uint32_t C, uint32_t F, uint32_t n, uint8_t *out, igdsp_frame_stats *stats,
+                            igdsp_chan_hold *hold, const uint8_t *gate, int variant, hipStream_t s);
+hipError_t launch_hold_update(const igdsp_frame_stats *stats, const uint16_t *len, uint32_t C, uint32_t F, uint32_t n,
+                              igdsp_chan_hold *hold, const uint8_t *gate, hipStream_t s);
+hipError_t launch_hold_reset(igdsp_chan_hold *hold, uint32_t C, const uint8_t *mask, hipStream_t s);
+hipError_t launch_gen_uniform(uint8_t *out, uint64_t n_bytes, uint64_t seed, uint64_t first_byte, hipStream_t s);
+hipError_t launch_stream_read(const LaunchCfg &cfg, const void *src, size_t bytes, uint64_t *sink, hipStream_t s);
+
+}  // namespace igdsp

@@ -1,0 +1,414 @@
+"""-m gpu parity tests: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs, against the committed golden fixtures, and — at BASELINE.json's
+full sizes — through size-independent properties.  Integer/byte results bit-exact;
+fp32 RMS within 1e-5 relative of the float64 definition (north_star tolerance)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from igate4xsoftphonedsp_amd import capi  # noqa: E402
+from tests import gpu_util as gu  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(device=0, max_channels=4096)
+    yield c
+    c.close()
+
+
+def _edge_frames(n=160):
+    ramp = (np.arange(n) & 0xFF).astype(np.uint8)
+    return [np.full(n, 0xFF, np.uint8), np.full(n, 0xD5, np.uint8), np.full(n, 0x00, np.uint8),
+            np.full(n, 0x80, np.uint8), np.full(n, 0x7F, np.uint8), np.full(n, 0x2A, np.uint8),
+            np.full(n, 0xAA, np.uint8), ramp, ramp[::-1].copy()]
+
+
+# ----------------------------------------------------------------------------- a1/a3/a5/a7
+@pytest.mark.parametrize("variant", [1, 2])
+def test_all_codes_both_laws_bit_exact(ctx, orc, variant):
+    """Every G.711 code, both laws, every lane/byte position: PCM and stats bit-exact."""
+    ctx.set_variant(variant)
+    C_, F_, n = 64, 5, 160
+    rng = np.random.default_rng(7)
+    payload = np.zeros((F_, C_, n), np.uint8)
+    for f in range(F_):
+        for c in range(C_):
+            payload[f, c] = np.roll(np.arange(n * 2, dtype=np.uint32)[:n] * (1 + (c % 3)) + 37 * c + 11 * f, c) & 0xFF
+    payload[0, :, :] = rng.permutation(np.tile(np.arange(256, dtype=np.uint8), C_ * n // 256 + 1)[: C_ * n]).reshape(C_, n)
+    codec = np.where(np.arange(C_) % 3 == 1, 8, 0).astype(np.uint8)
+    st, pcm, _ = gu.run_decode_meter(ctx, payload, codec, want_pcm=True)
+    est, epcm = orc.decode_meter(payload, codec, want_pcm=True)
+    assert np.array_equal(pcm, epcm)
+    gu.assert_stats_equal(st, est, n=n)
+    ctx.set_variant(0)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_config2_4096ch_uniform_and_edges(ctx, orc, variant):
+    """BASELINE config #2: 4 096 ch, F=16, D-uniform + D-edge, PCM store on, every int16 compared."""
+    ctx.set_variant(variant)
+    C_, F_, n = 4096, 16, 160
+    payload = orc.gen_uniform(F_ * C_ * n).reshape(F_, C_, n).copy()
+    edges = _edge_frames(n)
+    for i, e in enumerate(edges):            # D-edge rows sprinkled over channels of both laws
+        payload[i % F_, 100 + 2 * i] = e
+        payload[(i + 3) % F_, 101 + 2 * i] = e
+    codec = np.where(np.arange(C_) & 1, 8, 0).astype(np.uint8)
+    st, pcm, agg = gu.run_decode_meter(ctx, payload, codec, want_pcm=True, want_agg=True, rank=3)
+    est, epcm, eagg = orc.decode_meter(payload, codec, want_pcm=True, want_agg=True, rank=3)
+    assert np.array_equal(pcm, epcm)
+    gu.assert_stats_equal(st, est, n=n)
+    for f in ("sumsq", "samples", "frames", "n_silent", "n_clipped", "byte_mean_sum"):
+        assert int(agg[f]) == int(eagg[f]), f
+    assert agg["peak_slot"].tolist() == eagg["peak_slot"].tolist()
+    ctx.set_variant(0)
+
+
+def test_chunk_path_tail_and_wraparound(ctx, orc):
+    """n_frames not a multiple of 32 and C not a multiple of 32: tail clamping + channel wrap."""
+    for C_, F_ in ((50, 3), (33, 7), (32, 1), (127, 9), (96, 2)):
+        n = 160
+        payload = orc.gen_uniform(F_ * C_ * n, seed=C_ * 1000 + F_).reshape(F_, C_, n)
+        codec = np.where((np.arange(C_) * 7) % 5 < 2, 8, 0).astype(np.uint8)
+        st, pcm, agg = gu.run_decode_meter(ctx, payload, codec, want_pcm=True, want_agg=True)
+        est, epcm, eagg = orc.decode_meter(payload, codec, want_pcm=True, want_agg=True)
+        assert np.array_equal(pcm, epcm), (C_, F_)
+        gu.assert_stats_equal(st, est, n=n)
+        assert int(agg["sumsq"]) == int(eagg["sumsq"]) and int(agg["frames"]) == C_ * F_
+
+
+@pytest.mark.parametrize("n", [1, 3, 24, 159, 160, 164, 255, 256])
+def test_ragged_lengths_and_odd_frame_sizes(ctx, orc, n):
+    """Generic wave-per-frame path: any n in 1..256, per-frame valid length, empty slots."""
+    C_, F_ = 37, 4
+    rng = np.random.default_rng(n)
+    payload = orc.gen_uniform(F_ * C_ * n, seed=n).reshape(F_, C_, n)
+    codec = np.where(np.arange(C_) % 2, 8, 0).astype(np.uint8)
+    length = rng.integers(0, n + 1, size=(F_, C_)).astype(np.uint16)
+    length[0, 0] = 0
+    length[0, 1] = n
+    st, pcm, agg = gu.run_decode_meter(ctx, payload, codec, length=length, want_pcm=True, want_agg=True)
+    est, epcm, eagg = orc.decode_meter(payload, codec, length=length, want_pcm=True, want_agg=True)
+    assert np.array_equal(pcm, epcm)
+    gu.assert_stats_equal(st, est, n=length)
+    assert int(agg["samples"]) == int(length.sum()) == int(eagg["samples"])
+    assert int(agg["frames"]) == int((length > 0).sum())
+    # and without a length array
+    st, pcm, _ = gu.run_decode_meter(ctx, payload, codec, want_pcm=True)
+    est, epcm = orc.decode_meter(payload, codec, want_pcm=True)
+    assert np.array_equal(pcm, epcm)
+    gu.assert_stats_equal(st, est, n=n)
+
+
+def test_config1_golden_fixture_through_gpu(ctx, golden_dir):
+    """4 ch x 50 frames of the committed fixture: GPU vs values derived from audioop (not our oracle)."""
+    g = np.load(os.path.join(golden_dir, "config1_4ch_50f.npz"))
+    st, _, _ = gu.run_decode_meter(ctx, g["payload"], g["codec"])
+    assert np.array_equal(st["sumsq"], g["sumsq"])
+    assert np.array_equal(st["peak"].astype(np.int64), g["audioop_peak"])
+    assert np.array_equal(st["byte_mean"], g["byte_mean"])
+    ref = np.sqrt(g["sumsq"].astype(np.float64) / 160.0)
+    assert np.all(np.abs(st["rms"] - ref) <= 1e-5 * ref + 1e-30)
+
+
+def test_empty_batches_are_accepted(ctx):
+    torch = gu.torch_cuda()
+    d = gu.dev_zeros(16)
+    ctx.decode_meter(d, d, 0, 5, 160, d)
+    ctx.decode_meter(d, d, 5, 0, 160, d)
+    ctx.encode(d, d, 0, 0, 160, d)
+    torch.cuda.synchronize()
+
+
+def test_error_codes(ctx):
+    d = gu.dev_zeros(64 * 160)
+    L = ctx.L
+    assert L.igdsp_decode_meter(ctx.h, None, d.data_ptr(), None, 4, 1, 160, d.data_ptr(), None, None, 0, None) == -22
+    assert L.igdsp_decode_meter(ctx.h, d.data_ptr(), d.data_ptr(), None, 4, 1, 0, d.data_ptr(), None, None, 0, None) == -22
+    assert L.igdsp_decode_meter(ctx.h, d.data_ptr(), d.data_ptr(), None, 4, 1, 257, d.data_ptr(), None, None, 0, None) == -22
+    assert L.igdsp_decode_meter(ctx.h, d.data_ptr(), d.data_ptr(), None, 4, 1, 160, d.data_ptr(), None, None, 8, None) == -22
+    assert L.igdsp_decode_meter(None, d.data_ptr(), d.data_ptr(), None, 4, 1, 160, d.data_ptr(), None, None, 0, None) == -22
+    assert L.igdsp_encode(ctx.h, d.data_ptr(), d.data_ptr(), 4, 1, 160, d.data_ptr(), 7, None) == -22
+    assert L.igdsp_roundtrip_peakhold(ctx.h, d.data_ptr(), d.data_ptr(), 33, 1, 160, d.data_ptr(), d.data_ptr(), d.data_ptr(), None, 0, None) == -22
+    assert L.igdsp_destroy(None) == 0           # NULL tolerated like the reference's setters
+    assert L.igdsp_map_call(ctx.h, 1, 1 << 30) == -34
+    assert ctx.on_rtp_frame(4242, 0, b"\x00" * 160) == -2      # unmapped call id
+    assert ctx.on_rtp_frame(4242, 123, b"") == 0               # keep-alive: accepted, ignored
+    ctx.map_call(77, 0)
+    assert ctx.on_rtp_frame(77, 0, b"\x00" * 257) == -22
+    ctx.unmap_call(77)
+
+
+# ----------------------------------------------------------------------------- a2
+@pytest.mark.parametrize("variant", [capi.ENC_SUN16, capi.ENC_G191])
+def test_encode_exhaustive(ctx, orc, golden_dir, variant):
+    """All 65 536 int16 inputs, both laws, both encoder lineages: GPU == oracle, and the
+    G191 lineage == the frozen CPython-audioop table."""
+    torch = gu.torch_cuda()
+    aud = np.load(os.path.join(golden_dir, "g711_audioop.npz"))
+    C_, F_, n = 2, 256, 256
+    pcm = np.zeros((F_, C_, n), "<i2")
+    pcm[:, 0, :] = np.arange(-32768, 32768, dtype=np.int32).reshape(F_, n).astype("<i2")
+    pcm[:, 1, :] = pcm[:, 0, :]
+    codec = np.array([0, 8], np.uint8)
+    d_out = gu.dev_zeros(F_ * C_ * n, 0xEE)
+    ctx.encode(gu.to_dev(pcm), gu.to_dev(codec), C_, F_, n, d_out, variant=variant, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = gu.to_host(d_out, np.uint8, (F_, C_, n))
+    exp = orc.encode(pcm, codec, variant)
+    assert np.array_equal(got, exp)
+    if variant == capi.ENC_G191:
+        assert np.array_equal(got[:, 0, :].reshape(-1), aud["ulaw_encode_g191"])
+        assert np.array_equal(got[:, 1, :].reshape(-1), aud["alaw_encode_g191"])
+
+
+@pytest.mark.parametrize("n", [160, 7, 200])
+def test_encode_shapes(ctx, orc, n):
+    torch = gu.torch_cuda()
+    C_, F_ = 19, 3
+    rng = np.random.default_rng(5)
+    pcm = rng.integers(-32768, 32768, size=(F_, C_, n)).astype("<i2")
+    codec = np.where(np.arange(C_) % 3 == 0, 8, 0).astype(np.uint8)
+    for variant in (0, 1):
+        d_out = gu.dev_zeros(F_ * C_ * n, 0xEE)
+        ctx.encode(gu.to_dev(pcm), gu.to_dev(codec), C_, F_, n, d_out, variant=variant, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(gu.to_host(d_out, np.uint8, (F_, C_, n)), orc.encode(pcm, codec, variant))
+
+
+# ----------------------------------------------------------------------------- config #5
+@pytest.mark.parametrize("variant", [capi.ENC_SUN16, capi.ENC_G191])
+def test_roundtrip_peakhold_vs_oracle(ctx, orc, variant):
+    torch = gu.torch_cuda()
+    C_, F_, n = 256, 12, 160
+    codec = np.where(np.arange(C_) & 1, 8, 0).astype(np.uint8)
+    payload = orc.gen_speech(C_, F_, n, codec)
+    payload[3, 10] = 0x7F                     # mu-law negative zero: the one code that does not round-trip
+    payload[4, 11] = 0xD5
+    payload[5, 12] = 0x00
+    gate = (np.arange(C_) % 5 != 0).astype(np.uint8)
+    hold0 = gu.new_hold(C_)
+    hold0["peak_hold"][7] = 30000             # pre-existing state must be folded, not overwritten
+    hold0["count"][7] = 5
+    d_out, d_st, d_hold = gu.dev_zeros(F_ * C_ * n, 0xEE), gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.to_dev(hold0)
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.roundtrip_peakhold(gu.to_dev(payload), gu.to_dev(codec), C_, F_, n, d_out, d_st, d_hold, gate=gu.to_dev(gate), variant=variant, stream=s)
+    torch.cuda.synchronize()
+    ehold = hold0.copy().view(orc.CHAN_HOLD)
+    eout, est, ehold = orc.roundtrip_peakhold(payload, codec, ehold, gate=gate, variant=variant)
+    assert np.array_equal(gu.to_host(d_out, np.uint8, (F_, C_, n)), eout)
+    gu.assert_stats_equal(gu.to_host(d_st, capi.FRAME_STATS, (F_, C_)), est, n=n)
+    ghold = gu.to_host(d_hold, capi.CHAN_HOLD)
+    for f in capi.CHAN_HOLD.names:
+        assert np.array_equal(ghold[f], ehold[f]), f
+    # closed-set property: output == input except mu-law 0x7F -> 0xFF
+    exp = payload.copy()
+    mu = np.broadcast_to((codec == 0)[None, :, None], payload.shape)
+    exp[(payload == 0x7F) & mu] = 0xFF
+    assert np.array_equal(eout, exp)
+
+
+def test_hold_update_and_reset(ctx, orc):
+    torch = gu.torch_cuda()
+    C_, F_, n = 300, 9, 160
+    payload = orc.gen_uniform(F_ * C_ * n, seed=11).reshape(F_, C_, n)
+    codec = np.where(np.arange(C_) % 4 == 0, 8, 0).astype(np.uint8)
+    est = orc.decode_meter(payload, codec)
+    gate = (np.arange(C_) % 3 != 1).astype(np.uint8)
+    d_hold = gu.to_dev(gu.new_hold(C_))
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):                        # state persists across launches
+        ctx.hold_update(gu.to_dev(est), C_, F_, n, d_hold, gate=gu.to_dev(gate), stream=s)
+    torch.cuda.synchronize()
+    eh = orc.hold_new(C_)
+    for _ in range(2):
+        orc.hold_update(est, n, eh, gate=gate)
+    gh = gu.to_host(d_hold, capi.CHAN_HOLD)
+    for f in capi.CHAN_HOLD.names:
+        assert np.array_equal(gh[f], eh[f]), f
+    mask = (np.arange(C_) % 2).astype(np.uint8)
+    ctx.hold_reset(d_hold, C_, mask=gu.to_dev(mask), stream=s)
+    torch.cuda.synchronize()
+    gh2 = gu.to_host(d_hold, capi.CHAN_HOLD)
+    assert np.all(gh2["count"][mask == 1] == 0) and np.all(gh2["level_min"][mask == 1] == 255)
+    assert np.array_equal(gh2[mask == 0], gh[mask == 0])
+
+
+# ----------------------------------------------------------------------------- generators
+def test_gen_uniform_matches_oracle(ctx, orc):
+    torch = gu.torch_cuda()
+    for nbytes, first in ((4096, 0), (1000, 777), (13, 5), (160 * 64, 160 * 64 * 3)):
+        d = gu.dev_zeros(nbytes + 16, 0xEE)
+        ctx.gen_uniform(d, nbytes, seed=orc.SEED, first_byte=first, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = gu.to_host(d, np.uint8)
+        assert np.array_equal(got[:nbytes], orc.gen_uniform(nbytes, first_byte=first))
+        assert np.all(got[nbytes:] == 0xEE)
+
+
+# ----------------------------------------------------------------------------- single-frame path
+def test_staging_flush_poll_mirror_of_setIncomingRTP(ctx, orc):
+    """igdsp_on_rtp_frame takes exactly what setIncomingRTP reads from tp_adapter (callID,
+    payload_buff, payload_bufSize, pt).  trx->IncomingRTP == byte_mean must be bit-exact
+    with the restated loop (roip_ed137.cpp:6564-6568); percent follows audiometer.cpp:30-31."""
+    n = 160
+    calls = {5: 0, 9: 1, 70000: 2, -3: 3}       # incl. ids outside the direct table
+    for cid, ch in calls.items():
+        ctx.map_call(cid, ch)
+    ctx.reset_hold()
+    codec = {5: 0, 9: 8, 70000: 0, -3: 8}
+    frames = 6
+    hold = orc.hold_new(4)
+    for f in range(frames):
+        batch = {}
+        for cid, ch in calls.items():
+            if f == 2 and cid == 9:
+                assert ctx.on_rtp_frame(cid, 123, b"") == 0       # R2S keep-alive instead of audio
+                continue
+            ln = n if cid != -3 else 24 + f                        # short payloads (reference anticipates 24 / 164)
+            pl = orc.gen_uniform(ln, seed=1000 * f + ch)
+            assert ctx.on_rtp_frame(cid, codec[cid], pl.tobytes()) == 0
+            batch[ch] = (pl, codec[cid])
+        assert ctx.flush() == len(batch)
+        for cid, ch in calls.items():
+            lv = ctx.poll_call(cid)
+            if ch not in batch:
+                continue
+            pl, pt = batch[ch]
+            est = orc.decode_meter(pl.reshape(1, 1, -1), [pt])
+            assert lv.byte_mean == int(est["byte_mean"][0, 0]) == orc.byte_mean(pl)
+            assert lv.peak == int(est["peak"][0, 0])
+            ref = np.sqrt(float(est["sumsq"][0, 0]) / pl.size)
+            assert abs(lv.rms - ref) <= 1e-5 * ref + 1e-30
+            assert lv.percent == orc.percent(np.float32(lv.rms))
+            tmp = orc.hold_new(1)
+            orc.hold_update(est, pl.size, tmp)
+            hold["peak_hold"][ch] = max(hold["peak_hold"][ch], tmp["peak_hold"][0])
+            hold["count"][ch] += 1
+            hold["level_sum"][ch] += int(est["byte_mean"][0, 0])
+            hold["samples"][ch] += pl.size
+            assert lv.peak_hold == hold["peak_hold"][ch]
+    assert ctx.flush() == 0                                         # nothing staged: nothing processed
+    for cid, ch in calls.items():
+        h = ctx.get_hold(ch)
+        assert int(h["count"]) == int(hold["count"][ch]) and int(h["level_sum"]) == int(hold["level_sum"][ch])
+        assert int(h["samples"]) == int(hold["samples"][ch])
+        assert ctx.poll(ch).frames == hold["count"][ch]
+    ctx.reset_hold(1)
+    assert int(ctx.get_hold(1)["count"]) == 0 and int(ctx.get_hold(0)["count"]) == frames
+    for cid in calls:
+        ctx.unmap_call(cid)
+
+
+# ----------------------------------------------------------------------------- full-size properties
+@pytest.fixture(scope="module")
+def big(ctx):
+    """BASELINE configs[2]: 65 536 ch x 128 frames, mu-law, D-uniform generated on the device."""
+    torch = gu.torch_cuda()
+    C_, F_, n = 65536, 128, 160
+    d_pl = torch.empty((F_ * C_ * n,), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.gen_uniform(d_pl, F_ * C_ * n, stream=s)
+    d_cd = torch.zeros((C_,), dtype=torch.uint8, device="cuda")
+    d_st = gu.dev_zeros(F_ * C_ * 16, 0xEE)
+    d_agg = gu.dev_zeros(capi.AGGREGATE.itemsize)
+    ctx.agg_reset(d_agg, stream=s)
+    ctx.decode_meter(d_pl, d_cd, C_, F_, n, d_st, agg=d_agg, rank=0, stream=s)
+    torch.cuda.synchronize()
+    return dict(C=C_, F=F_, n=n, d_pl=d_pl, d_cd=d_cd, d_st=d_st, agg=gu.to_host(d_agg, capi.AGGREGATE)[0])
+
+
+def test_full_size_checksum_of_checksums(big):
+    """The launch aggregate (device atomics) equals the sum over the per-frame records."""
+    st = gu.to_host(big["d_st"], capi.FRAME_STATS)
+    agg = big["agg"]
+    assert int(agg["frames"]) == st.size == big["C"] * big["F"]
+    assert int(agg["samples"]) == st.size * big["n"]
+    assert int(agg["sumsq"]) == int(st["sumsq"].sum(dtype=np.uint64))   # <= 8.4e6 * 1.66e11 < 2^64
+    assert int(agg["byte_mean_sum"]) == int(st["byte_mean"].astype(np.int64).sum())
+    assert int(agg["peak_slot"][0]) == int(st["peak"].max())
+    assert int(agg["n_silent"]) == int((st["flags"] & 1).astype(np.int64).sum())
+    assert int(agg["n_clipped"]) == int(((st["flags"] >> 2) & 1).astype(np.int64).sum())
+    ref = np.sqrt(st["sumsq"].astype(np.float64) / big["n"])
+    assert np.all(np.abs(st["rms"] - ref) <= 1e-5 * ref + 1e-30)
+
+
+def test_full_size_sampled_frames_vs_oracle(big, orc):
+    """Random frames (plus first/last chunks) of the 1.34 GB batch re-done by the oracle from the
+    shard-invariant generator — no 1.3 GB host copy needed."""
+    C_, F_, n = big["C"], big["F"], big["n"]
+    st = gu.to_host(big["d_st"], capi.FRAME_STATS)
+    rng = np.random.default_rng(3)
+    idx = np.unique(np.concatenate([np.arange(64), np.arange(C_ * F_ - 64, C_ * F_), rng.integers(0, C_ * F_, 3000)]))
+    for fi in idx:
+        pl = orc.gen_uniform(n, first_byte=int(fi) * n)
+        e = orc.decode_meter(pl.reshape(1, 1, n), [0])[0, 0]
+        g = st[fi]
+        assert (int(g["sumsq"]), int(g["peak"]), int(g["byte_mean"]), int(g["flags"])) == \
+               (int(e["sumsq"]), int(e["peak"]), int(e["byte_mean"]), int(e["flags"])), fi
+
+
+def test_full_size_variants_agree(ctx, big):
+    """wave-per-frame (variant 1) and chunk32 (variant 2) produce identical records at full size."""
+    torch = gu.torch_cuda()
+    d_st1 = gu.dev_zeros(big["F"] * big["C"] * 16, 0xEE)
+    ctx.set_variant(1)
+    ctx.decode_meter(big["d_pl"], big["d_cd"], big["C"], big["F"], big["n"], d_st1, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ctx.set_variant(0)
+    assert torch.equal(d_st1, big["d_st"])
+
+
+def test_full_size_roundtrip_idempotence_config5(ctx, big, orc):
+    """BASELINE configs[4]: 65 536 ch mixed A-law/mu-law, fused decode->stats->encode + peak hold.
+    Properties: codes reproduce (except mu 0x7F->0xFF); running the pass twice doubles the window
+    sums and leaves peak-hold / max / min unchanged; hold equals a fold of the per-frame records."""
+    torch = gu.torch_cuda()
+    C_, F_, n = big["C"], 16, big["n"]
+    d_pl = big["d_pl"][: F_ * C_ * n]
+    codec = np.where(np.arange(C_) & 1, 8, 0).astype(np.uint8)
+    d_cd = gu.to_dev(codec)
+    d_out, d_st = torch.empty_like(d_pl), gu.dev_zeros(F_ * C_ * 16, 0xEE)
+    d_hold = gu.to_dev(gu.new_hold(C_))
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.roundtrip_peakhold(d_pl, d_cd, C_, F_, n, d_out, d_st, d_hold, stream=s)
+    torch.cuda.synchronize()
+    h1 = gu.to_host(d_hold, capi.CHAN_HOLD).copy()
+    src = d_pl.view(F_, C_, n)
+    mu = torch.from_numpy(codec == 0).cuda()[None, :, None]
+    exp = torch.where((src == 0x7F) & mu, torch.full_like(src, 0xFF), src)
+    assert torch.equal(d_out.view(F_, C_, n), exp)
+    st = gu.to_host(d_st, capi.FRAME_STATS, (F_, C_))
+    assert np.array_equal(h1["peak_hold"], st["peak"].max(axis=0))
+    assert np.array_equal(h1["level_max"], st["byte_mean"].max(axis=0))
+    assert np.array_equal(h1["level_min"], st["byte_mean"].min(axis=0))
+    assert np.array_equal(h1["level_sum"], st["byte_mean"].astype(np.uint32).sum(axis=0))
+    assert np.array_equal(h1["sumsq_acc"], st["sumsq"].sum(axis=0))
+    assert np.all(h1["count"] == F_)
+    d_out2 = torch.empty_like(d_out)
+    ctx.roundtrip_peakhold(d_out, d_cd, C_, F_, n, d_out2, d_st, d_hold, stream=s)   # second pass over its own output
+    torch.cuda.synchronize()
+    assert torch.equal(d_out2, d_out)                                                 # idempotent after one pass
+    h2 = gu.to_host(d_hold, capi.CHAN_HOLD)
+    assert np.all(h2["count"] == 2 * F_) and np.array_equal(h2["sumsq_acc"], 2 * h1["sumsq_acc"])
+    assert np.array_equal(h2["peak_hold"], h1["peak_hold"])
+    # the decode_meter kernel sees the same frames identically
+    d_st2 = gu.dev_zeros(F_ * C_ * 16, 0xEE)
+    ctx.decode_meter(d_out, d_cd, C_, F_, n, d_st2, stream=s)
+    torch.cuda.synchronize()
+    st2 = gu.to_host(d_st2, capi.FRAME_STATS, (F_, C_))
+    for f in ("sumsq", "peak", "flags"):
+        assert np.array_equal(st2[f], st[f]), f
+    # a sample of mixed-law frames against the oracle
+    rng = np.random.default_rng(9)
+    for fi in rng.integers(0, C_ * F_, 500):
+        f, c = divmod(int(fi), C_)
+        pl = orc.gen_uniform(n, first_byte=int(fi) * n)
+        e = orc.decode_meter(pl.reshape(1, 1, n), [int(codec[c])])[0, 0]
+        assert (int(st[f, c]["sumsq"]), int(st[f, c]["peak"]), int(st[f, c]["byte_mean"])) == \
+               (int(e["sumsq"]), int(e["peak"]), int(e["byte_mean"]))
