@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="0 tuned default, 1 wave-per-frame, 2 chunk32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-agg", action="store_true", help="experiment: skip the launch aggregate (N=1 only)")
     ap.add_argument("--stream-calib", action="store_true", help="also time the read-only stream kernel")
     return ap.parse_args()
 
@@ -105,9 +106,11 @@ def main():
     C_total = C_ * world
     ctx = capi.Context(device=local, max_channels=1024)
     ctx.set_variant(args.variant)
-    main_s = torch.cuda.current_stream()
-    comm_s = torch.cuda.Stream()
+    main_s = torch.cuda.Stream()       # explicit launch stream: kernels, resets and timers all live on it
+    comm_s = torch.cuda.Stream()       # side stream for the per-launch all-reduce
+    torch.cuda.set_stream(main_s)
     hs = main_s.cuda_stream
+    assert hs != 0
 
     # ---- synthetic input, generated on the device, shard-invariant: this rank holds
     # channels [rank*C, (rank+1)*C) of the global [F][C_total][160] D-uniform array.
@@ -129,7 +132,7 @@ def main():
         aggs[b].zero_()
         if timer is not None:
             timer.start(hs)
-        ctx.decode_meter(d_pl, d_cd, C_, F_, n, d_st, pcm=d_pcm, agg=aggs[b], rank=rank, stream=hs)
+        ctx.decode_meter(d_pl, d_cd, C_, F_, n, d_st, pcm=d_pcm, agg=None if args.no_agg else aggs[b], rank=rank, stream=hs)
         if timer is not None:
             timer.stop(hs)
         if world > 1:                              # node-wide sum / peak: one 112-byte all-reduce per launch, side stream
@@ -172,7 +175,7 @@ def main():
     value = total_samples / dt / 1e6
     bps = BYTES_PER_SAMPLE[args.mode]
     achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9
-    kernel_name = "k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk32"
+    kernel_name = "k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64"
 
     out = {
         "metric": "Msamples/s G.711 decode+RMS, 65536ch@8kHz; %HBM roofline at 1/2/4/8 GPU",

@@ -47,6 +47,8 @@ def build(force: bool = False, save_asm: bool = False, verbose: bool = False) ->
             "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-result",
             "-o", LIB, *srcs,
         ]
+        extra = os.environ.get("IGDSP_CXXFLAGS", "").split()      # A/B experiments: -DIGDSP_...=N
+        cmd[1:1] = extra
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True, cwd=PKG)

@@ -106,6 +106,13 @@ def load() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -m igate4xsoftphonedsp_amd.build` "
                 "(there is no CPU fallback for the igdsp kernels)"
             )
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7.  Import torch first so
+        # libigdsp.so's DT_NEEDED resolves to the runtime that also owns the tensors whose device pointers
+        # we are handed (loading ours first leaves torch without a usable device).  Plumbing only.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in PROTOTYPES:
             fn = getattr(L, name)          # AttributeError here == ABI symbol missing

@@ -77,7 +77,9 @@ static int fail(igdsp_ctx *ctx, int code, const char *what, hipError_t e = hipSu
         if (e_ != hipSuccess) return fail((ctx), IGDSP_EDEVICE, #call, e_);   \
     } while (0)
 
-static inline hipStream_t pick(igdsp_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+// NULL means what it means everywhere in HIP: the legacy default (null) stream, so a caller that
+// passes nothing stays ordered with its own default-stream work (e.g. torch tensors it just filled).
+static inline hipStream_t pick(igdsp_ctx *, void *stream) { return (hipStream_t)stream; }
 static inline LaunchCfg cfg_of(const igdsp_ctx *ctx) { return LaunchCfg{ctx->cus}; }
 
 extern "C" {
@@ -395,6 +397,17 @@ int igdsp_stream_read(igdsp_ctx *ctx, const void *d_src, size_t bytes, uint64_t 
     if (!ctx || !d_src || !d_sink || (reinterpret_cast<uintptr_t>(d_src) & 15u)) return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_stream_read(cfg_of(ctx), d_src, bytes, d_sink, pick(ctx, stream)));
+    return IGDSP_OK;
+}
+
+// Diagnostic-only (not in include/igdsp.h): cycle stamps of the chunk32 kernel, 8 x u64 per wavefront
+// {t_begin, t_lut_ready, t_end, sum load-wait, sum process, iterations, sum frame-reduce, xcc id}.
+int igdsp_internal_diag_chunk32(igdsp_ctx *ctx, const uint8_t *d_payload, const uint8_t *d_codec, uint32_t C, uint32_t F,
+                                igdsp_frame_stats *d_stats, uint64_t *d_diag, void *stream)
+{
+    if (!ctx || !d_payload || !d_codec || !d_stats || !d_diag || C < 32) return IGDSP_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_diag_chunk32(cfg_of(ctx), d_payload, d_codec, C, F, d_stats, d_diag, pick(ctx, stream)));
     return IGDSP_OK;
 }
 

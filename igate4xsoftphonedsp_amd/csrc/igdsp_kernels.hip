@@ -39,6 +39,20 @@ __device__ __forceinline__ uint4 ld_stream(const uint4 *p)
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// write-once 16-byte store (records / PCM are never re-read by this launch)
+#ifndef IGDSP_NT_STORE
+#define IGDSP_NT_STORE 1
+#endif
+__device__ __forceinline__ void st_stream(uint4 *p, const uint4 v)
+{
+#if IGDSP_NT_STORE
+    u32x4_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t *>(p));
+#else
+    *p = v;
+#endif
+}
+
 __device__ __forceinline__ uint32_t full_scale(bool alaw) { return alaw ? 32256u : 32124u; }
 
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m)
@@ -49,12 +63,16 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m)
     return ((uint64_t)hi << 32) | lo;
 }
 
-__device__ __forceinline__ void agg_commit(igdsp_aggregate *agg, uint32_t rank, uint64_t sumsq, uint64_t samples,
-                                           uint32_t frames, uint32_t n_silent, uint32_t n_clipped,
-                                           uint32_t bm_sum, uint32_t peak)
+// Launch aggregate: wave butterfly -> one LDS slot per wave -> wave 0 folds the block -> ONE set of
+// device-scope integer atomics per BLOCK (exact, order-independent u64 add / max).  Same-line atomics
+// serialise at roughly 90 per microsecond, so per-wave commits (4096 waves x 7 words) cost ~0.3 ms;
+// per-block commits keep it to a few microseconds that overlap with other blocks' tails.
+// `slots` = nwaves x 4 uint2 of LDS.  Must be reached by every thread of the block.
+__device__ __forceinline__ void agg_commit_block(igdsp_aggregate *agg, uint32_t rank, uint2 *slots, uint32_t nwaves,
+                                                 uint64_t sumsq, uint64_t samples, uint32_t frames, uint32_t n_silent,
+                                                 uint32_t n_clipped, uint32_t bm_sum, uint32_t peak)
 {
-    // wave-level butterfly, then one set of device-scope integer atomics per wave
-    // (exact and order-independent: u64 adds and max).
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         sumsq += shfl_xor_u64(sumsq, m);
@@ -65,14 +83,41 @@ __device__ __forceinline__ void agg_commit(igdsp_aggregate *agg, uint32_t rank, 
         bm_sum += (uint32_t)__shfl_xor((int)bm_sum, m, 64);
         peak = max(peak, (uint32_t)__shfl_xor((int)peak, m, 64));
     }
-    if ((threadIdx.x & 63) == 0 && frames != 0) {
-        atomicAdd((unsigned long long *)&agg->sumsq, (unsigned long long)sumsq);
-        atomicAdd((unsigned long long *)&agg->samples, (unsigned long long)samples);
-        atomicAdd((unsigned long long *)&agg->frames, (unsigned long long)frames);
-        atomicAdd((unsigned long long *)&agg->n_silent, (unsigned long long)n_silent);
-        atomicAdd((unsigned long long *)&agg->n_clipped, (unsigned long long)n_clipped);
-        atomicAdd((unsigned long long *)&agg->byte_mean_sum, (unsigned long long)bm_sum);
-        atomicMax((unsigned long long *)&agg->peak_slot[rank & (IGDSP_AGG_MAX_RANKS - 1)], (unsigned long long)peak);
+    __syncthreads();                       // every wave is done with its LDS strip
+    if (lane == 0) {
+        slots[wave * 4 + 0] = make_uint2((uint32_t)sumsq, (uint32_t)(sumsq >> 32));
+        slots[wave * 4 + 1] = make_uint2((uint32_t)samples, (uint32_t)(samples >> 32));
+        slots[wave * 4 + 2] = make_uint2(frames, n_silent);
+        slots[wave * 4 + 3] = make_uint2(n_clipped | 0u, bm_sum);
+    }
+    // peak rides in a fifth word: reuse slot 2/3 would overflow nothing, keep it simple and separate
+    __shared__ uint32_t peak_slots[kWavesPerBlock];
+    if (lane == 0) peak_slots[wave] = peak;
+    __syncthreads();
+    if (wave == 0) {
+        uint64_t s = 0, sm = 0;
+        uint32_t fr = 0, sil = 0, cl = 0, bm = 0, pk = 0;
+        if (lane < nwaves) {
+            const uint2 a = slots[lane * 4 + 0], b = slots[lane * 4 + 1], c = slots[lane * 4 + 2], d = slots[lane * 4 + 3];
+            s = ((uint64_t)a.y << 32) | a.x; sm = ((uint64_t)b.y << 32) | b.x;
+            fr = c.x; sil = c.y; cl = d.x; bm = d.y; pk = peak_slots[lane];
+        }
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {   // nwaves <= 16
+            s += shfl_xor_u64(s, m); sm += shfl_xor_u64(sm, m);
+            fr += (uint32_t)__shfl_xor((int)fr, m, 64); sil += (uint32_t)__shfl_xor((int)sil, m, 64);
+            cl += (uint32_t)__shfl_xor((int)cl, m, 64); bm += (uint32_t)__shfl_xor((int)bm, m, 64);
+            pk = max(pk, (uint32_t)__shfl_xor((int)pk, m, 64));
+        }
+        if (lane == 0 && fr != 0) {
+            atomicAdd((unsigned long long *)&agg->sumsq, (unsigned long long)s);
+            atomicAdd((unsigned long long *)&agg->samples, (unsigned long long)sm);
+            atomicAdd((unsigned long long *)&agg->frames, (unsigned long long)fr);
+            atomicAdd((unsigned long long *)&agg->n_silent, (unsigned long long)sil);
+            atomicAdd((unsigned long long *)&agg->n_clipped, (unsigned long long)cl);
+            atomicAdd((unsigned long long *)&agg->byte_mean_sum, (unsigned long long)bm);
+            atomicMax((unsigned long long *)&agg->peak_slot[rank & (IGDSP_AGG_MAX_RANKS - 1)], (unsigned long long)pk);
+        }
     }
 }
 
@@ -109,10 +154,12 @@ __device__ __forceinline__ igdsp_frame_stats make_stats(uint64_t sumsq, uint32_t
 // ============================================================================
 __global__ __launch_bounds__(256) void k_meter_wave_per_frame(
     const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, const uint16_t *__restrict__ len,
-    uint32_t C, uint32_t n_frames, uint32_t n, igdsp_frame_stats *__restrict__ stats, int16_t *__restrict__ pcm,
-    igdsp_aggregate *agg, uint32_t rank)
+    uint32_t C, uint32_t first_frame, uint32_t n_frames, uint32_t n, igdsp_frame_stats *__restrict__ stats,
+    int16_t *__restrict__ pcm, igdsp_aggregate *agg, uint32_t rank)
 {
+    // frames [first_frame, n_frames) of the batch; all pointers are the batch bases
     __shared__ int16_t lut[2][256];
+    __shared__ uint2 agg_slots[4 * 4];
     for (uint32_t i = threadIdx.x; i < 512u; i += 256u) {
         const uint32_t code = i & 255u;
         const int ax = (int)((i >> 8) ? alaw_abs(code) : ulaw_abs(code));
@@ -126,7 +173,7 @@ __global__ __launch_bounds__(256) void k_meter_wave_per_frame(
     uint64_t a_sumsq = 0, a_samples = 0;
     uint32_t a_frames = 0, a_sil = 0, a_clip = 0, a_bm = 0, a_peak = 0;
 
-    for (uint32_t fi = blockIdx.x * 4u + wave; fi < n_frames; fi += gridDim.x * 4u) {
+    for (uint32_t fi = first_frame + blockIdx.x * 4u + wave; fi < n_frames; fi += gridDim.x * 4u) {
         const uint32_t c = fi % C;
         const bool alaw = codec[c] == IGDSP_PT_PCMA;
         uint32_t l = len ? (uint32_t)len[fi] : n;
@@ -191,7 +238,7 @@ __global__ __launch_bounds__(256) void k_meter_wave_per_frame(
             stats[fi] = st;
         }
     }
-    if (agg != nullptr) agg_commit(agg, rank, a_sumsq, a_samples, a_frames, a_sil, a_clip, a_bm, a_peak);
+    if (agg != nullptr) agg_commit_block(agg, rank, agg_slots, 4u, a_sumsq, a_samples, a_frames, a_sil, a_clip, a_bm, a_peak);
 }
 
 // ============================================================================
@@ -287,23 +334,126 @@ __device__ __forceinline__ uint32_t probe_fail(const uint4 d, const uint32_t pma
 
 __device__ __forceinline__ uint32_t probe_mask(uint32_t q)   // q = piece index within the frame
 {
-    return q == 1u ? 0x000000FFu : (q == 3u ? 0x0000FF00u : (q == 2u ? 0x00FF0000u : 0u));
+    return (q == 1u ? 0x000000FFu : 0u) | (q == 3u ? 0x0000FF00u : 0u) | (q == 2u ? 0x00FF0000u : 0u);
 }
 
-template <bool STORE_PCM, bool AGG>
-__global__ __launch_bounds__(kBlockThreads) void k_meter_chunk32(
-    const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t n_frames,
-    igdsp_frame_stats *__restrict__ stats, int16_t *__restrict__ pcm, igdsp_aggregate *agg, uint32_t rank)
+__device__ __forceinline__ uint64_t now_cycles() { return __builtin_readcyclecounter(); }
+
+// Frame record for the tuned n == 160 path.  sumsq = 16 * s with s < 2^34; rms = sqrt(s / 10):
+// two u32->f32 converts + one fma, one multiply, one v_sqrt_f32 (1 ulp) — total relative error
+// < 4e-7 against the float64 definition, inside the 1e-5 contract; every integer field is exact.
+__device__ __forceinline__ uint4 pack_stats160(uint64_t s, uint32_t peak, uint32_t bsum, bool alaw, bool probe,
+                                               uint32_t &byte_mean, uint32_t &flags)
 {
-    __shared__ uint2 lds[kLutEntries + kWavesPerBlock * kPiecesPerChunk];   // 64 KiB + 40 KiB
+    byte_mean = bsum / 160u;
+    flags = (peak <= 8u ? IGDSP_FLAG_SILENT : 0u) | (probe ? IGDSP_FLAG_PROBE_D5 : 0u) |
+            (peak == full_scale(alaw) ? IGDSP_FLAG_CLIPPED : 0u);
+    const float fs = fmaf((float)(uint32_t)(s >> 32), 4294967296.0f, (float)(uint32_t)s);
+    const float rms = __builtin_amdgcn_sqrtf(fs * 0.1f);
+    const uint64_t sumsq = s << 4;
+    return make_uint4((uint32_t)sumsq, (uint32_t)(sumsq >> 32), __float_as_uint(rms), peak | (byte_mean << 16) | (flags << 24));
+}
+
+// ----------------------------------------------------------------------------
+// One half (32 frames = five 16-byte pieces per lane) of a super-chunk: expand, square-accumulate,
+// peak, byte-sum, probe; one strip entry per piece.  The 80 LUT reads are software-pipelined in
+// units of 8 samples: unit u+1's eight ds_read_b64 are in flight while unit u is folded, so a wave
+// hides most LDS latency by itself (at most 16 LDS reads outstanding = the lgkmcnt limit).
+// ----------------------------------------------------------------------------
+template <bool STORE_PCM>
+__device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half, uint4 (&d)[kLoadsPerChunk],
+                                             const uint32_t (&lm)[kLoadsPerChunk], const uint32_t (&pm)[kLoadsPerChunk],
+                                             const uint32_t off, const uint32_t lane, uint4 *pcm_half, const uint4 *refill)
+{
+    // `refill` = this lane's first piece of the NEXT super-chunk's same half: piece j's register is
+    // reloaded the moment piece j has been folded, so the five loads trickle out evenly and get
+    // most of an iteration of lead time.
+    uint2 e[2][8];
+    uint32_t wa[2], wb[2];
+    auto issue = [&](int u) {
+        const int j = u >> 1, k = u & 1;
+        wa[k] = (u & 1) ? d[j].z : d[j].x;
+        wb[k] = (u & 1) ? d[j].w : d[j].y;
+        const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lm[j], tb = (wb[k] & 0x7F7F7F7Fu) | lm[j];
+        e[k][0] = lut_at(lut, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lut, ta, off, 0x0C0C0500u);
+        e[k][2] = lut_at(lut, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lut, ta, off, 0x0C0C0700u);
+        e[k][4] = lut_at(lut, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lut, tb, off, 0x0C0C0500u);
+        e[k][6] = lut_at(lut, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lut, tb, off, 0x0C0C0700u);
+    };
+    uint32_t sum = 0, peak = 0, bsum = 0;
+    uint32_t o[8];
+    issue(0);
+#pragma unroll
+    for (int u = 0; u < 2 * kLoadsPerChunk; ++u) {
+        const int j = u >> 1, k = u & 1;
+        if (u + 1 < 2 * kLoadsPerChunk) issue(u + 1);
+        __builtin_amdgcn_sched_barrier(0);      // keep the next unit's reads ahead of this unit's folds
+        bsum = __builtin_amdgcn_sad_u8(wa[k], 0u, bsum);
+        bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
+        sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
+        sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
+        peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
+        peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
+        if (STORE_PCM) {
+            o[4 * k + 0] = pack_pcm(wa[k], 0, e[k][0].y, e[k][1].y); o[4 * k + 1] = pack_pcm(wa[k], 2, e[k][2].y, e[k][3].y);
+            o[4 * k + 2] = pack_pcm(wb[k], 0, e[k][4].y, e[k][5].y); o[4 * k + 3] = pack_pcm(wb[k], 2, e[k][6].y, e[k][7].y);
+        }
+        if (k == 1) {                           // piece j complete
+            strip_half[j * 64 + lane] = make_uint2(sum, peak | (bsum << 16) | probe_fail(d[j], pm[j]));
+            if (STORE_PCM) {
+                uint4 *op = pcm_half + 2u * ((uint32_t)j * 64u + lane);
+                st_stream(op, make_uint4(o[0], o[1], o[2], o[3]));
+                st_stream(op + 1, make_uint4(o[4], o[5], o[6], o[7]));
+            }
+            d[j] = ld_stream(refill + j * 64);
+            sum = 0; peak = 0; bsum = 0;
+        }
+    }
+}
+
+// ============================================================================
+// Variant 2 (default for n == 160) — "chunk64".
+//
+// Work unit: a super-chunk of 64 consecutive channel-frames = 10 240 contiguous bytes, owned by ONE
+// wavefront and fetched as ten wave-wide 16 B/lane loads (1 KiB per instruction, fully coalesced).
+// A 16-byte piece never straddles a frame (160 = 10 x 16), so each lane reduces its ten pieces
+// privately; the 10 pieces of every frame are then folded by that frame's lane (all 64 lanes busy)
+// through a per-wave LDS strip, and 64 x 16 B records leave as one 1 KiB store.
+//
+// Pipeline per wave: registers X / Y hold the two 32-frame halves.  While half X is expanded the
+// loads refilling Y (issued half an iteration earlier) are in flight, and vice versa; no load in the
+// steady-state loop is conditional (tail pieces are clamped, the final prefetch re-reads the current
+// super-chunk) so the compiler keeps counted vmcnt waits.
+//
+// Balance: block b owns super-chunks b, b+G, b+2G, ...; its 16 waves pull the next one from an LDS
+// counter, so the waves of a CU finish within one iteration of each other.
+// ============================================================================
+constexpr int kSuperFrames = 2 * kChunkFrames;                 // 64
+constexpr int kStripEntries = kSuperFrames * kPiecesPerFrame;  // 640 x 8 B = 5 KiB per wave
+constexpr int kChunkLdsEntries = kLutEntries + kWavesPerBlock * kStripEntries;   // 64 KiB + 80 KiB
+
+// DIAG: a separate diagnostic instantiation (never the shipped path) that stamps where a
+// wave's cycles go; the stamps leave only through `diag`, no output is computed from them.
+template <bool STORE_PCM, bool AGG, bool DIAG = false>
+__global__ __launch_bounds__(kBlockThreads) void k_meter_chunk64(
+    const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t n_frames,
+    igdsp_frame_stats *__restrict__ stats, int16_t *__restrict__ pcm, igdsp_aggregate *agg, uint32_t rank,
+    uint64_t *__restrict__ diag = nullptr)
+{
+    __shared__ uint2 lds[kChunkLdsEntries];
+    __shared__ uint32_t next_item;
+    uint64_t d_t0 = 0, d_t1 = 0, d_iter = 0, d_rt0 = 0, d_setup = 0, d_px = 0, d_py = 0, d_red = 0;
+    if (DIAG) { d_t0 = now_cycles(); d_rt0 = __builtin_amdgcn_s_memrealtime(); }
     fill_lut(lds);
+    if (threadIdx.x == 0) next_item = kWavesPerBlock;            // items 0..15 are the waves' first picks
     __syncthreads();
+    if (DIAG) d_t1 = now_cycles();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2 *strip = lds + kLutEntries + wave * kPiecesPerChunk;
+    uint2 *strip = lds + kLutEntries + wave * kStripEntries;
     const uint32_t off = (lane & 31u) * 8u;
 
-    uint32_t fr[kLoadsPerChunk], pm[kLoadsPerChunk];   // frame-in-chunk / probe mask of this lane's five pieces
+    uint32_t fr[kLoadsPerChunk], pm[kLoadsPerChunk];   // frame-in-half / probe mask of this lane's five pieces per half
 #pragma unroll
     for (int j = 0; j < kLoadsPerChunk; ++j) {
         const uint32_t p = (uint32_t)j * 64u + lane;
@@ -311,94 +461,99 @@ __global__ __launch_bounds__(kBlockThreads) void k_meter_chunk32(
         pm[j] = probe_mask(p - fr[j] * 10u);
     }
 
-    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
-    const uint32_t wave_id = wave * gridDim.x + blockIdx.x;      // neighbouring chunks -> different CUs
-    const uint32_t n_chunks = (n_frames + kChunkFrames - 1u) / kChunkFrames;
-    if (wave_id >= n_chunks) return;                             // (after the only block-wide barrier)
-    const uint32_t last_piece = n_frames * kPiecesPerFrame - 1u; // tail pieces are clamped, never predicated:
-    const uint4 *src16 = reinterpret_cast<const uint4 *>(payload); // every lane always loads => counted vmcnt survives
-    uint32_t c_base = (uint32_t)(((uint64_t)wave_id * kChunkFrames) % C);
-    const uint32_t c_step = (uint32_t)(((uint64_t)total_waves * kChunkFrames) % C);
+    const uint32_t G = gridDim.x;
+    const uint32_t n_super = n_frames / kSuperFrames;             // the launcher hands over whole super-chunks only:
+    const uint4 *src16 = reinterpret_cast<const uint4 *>(payload); // no tail predicate anywhere in the loop
 
     uint64_t a_sumsq = 0;
     uint32_t a_frames = 0, a_sil = 0, a_clip = 0, a_bm = 0, a_peak = 0;
 
-    auto fetch = [&](uint4 (&dst)[kLoadsPerChunk], uint32_t &pt, uint32_t ck, uint32_t cb) {
-        const uint32_t p0 = ck * (uint32_t)kPiecesPerChunk + lane;
+    auto fetch_half = [&](uint4 (&dst)[kLoadsPerChunk], uint32_t sidx, uint32_t half) {
+        const uint32_t p0 = sidx * (uint32_t)kStripEntries + half * (uint32_t)kPiecesPerChunk + lane;
 #pragma unroll
-        for (int j = 0; j < kLoadsPerChunk; ++j) dst[j] = ld_stream(src16 + min(p0 + (uint32_t)j * 64u, last_piece));
-        uint32_t cme = cb + (lane & 31u);                        // codec id (RTP PT) of this lane's own frame
-        if (cme >= C) cme -= C;
-        pt = codec[cme];
+        for (int j = 0; j < kLoadsPerChunk; ++j) dst[j] = ld_stream(src16 + (p0 + (uint32_t)j * 64u));
+    };
+    auto fetch_pt = [&](uint32_t sidx) {                         // codec id (RTP PT) of this lane's own frame
+        const uint32_t c = (sidx * (uint32_t)kSuperFrames + lane) % C;     // < 2^32: the ABI caps C*F
+        return (uint32_t)codec[c];
+    };
+    auto grab = [&]() {                                          // next item of this block (wave-uniform)
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(&next_item, 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
     };
 
-    auto process = [&](const uint4 (&cur)[kLoadsPerChunk], const uint32_t cur_pt, const uint32_t ck) {
-        const uint32_t f0 = ck * kChunkFrames;
-        const uint32_t my_alaw = (cur_pt == IGDSP_PT_PCMA) ? 1u : 0u;   // frame lanes 0..31; broadcast to piece lanes
+    uint32_t sidx = blockIdx.x + wave * G;
+    if (sidx < n_super) {
+        uint4 X[kLoadsPerChunk], Y[kLoadsPerChunk];
+        uint32_t cur_pt = fetch_pt(sidx);          // issue order pt, X, Y — the same in the prologue and in the loop,
+        fetch_half(X, sidx, 0);                    // so the waits at the loop head stay counted (vmcnt(N), not 0)
+        fetch_half(Y, sidx, 1);
+        uint32_t k_next = grab();                  // the item after this one (pulled one iteration ahead of use)
+        for (;;) {
+            uint64_t d_a = 0, d_b = 0, d_c = 0, d_d = 0;
+            if (DIAG) d_a = now_cycles();
+            const uint32_t s_next = blockIdx.x + k_next * G;
+            const bool has_next = s_next < n_super;
+            const uint32_t s_load = has_next ? s_next : sidx;    // last round: harmless re-read (cache hit), keeps loads unconditional
+            const uint32_t f0 = sidx * kSuperFrames;
+            // law of frame l of this super-chunk lives in lane l; one ballot turns it into a 64-bit wave mask,
+            // and each piece picks its frame's bit (no cross-lane traffic per piece)
+            const bool my_alaw = cur_pt == IGDSP_PT_PCMA;
+            const uint64_t amask = __ballot(my_alaw);
+            const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
+            uint32_t lm0[kLoadsPerChunk], lm1[kLoadsPerChunk];
 #pragma unroll
-        for (int j = 0; j < kLoadsPerChunk; ++j) {
-            const uint32_t alaw = (uint32_t)__shfl((int)my_alaw, (int)fr[j], 64);
-            const uint32_t lawmask = alaw ? 0x80808080u : 0u;
-            uint32_t sum = 0, peak = 0, bsum = 0;
-            uint4 o0, o1;
-            piece16<STORE_PCM>(lds, cur[j], lawmask, off, sum, peak, bsum, o0, o1);
-            strip[j * 64 + lane] = make_uint2(sum, peak | (bsum << 16) | probe_fail(cur[j], pm[j]));
-            if (STORE_PCM && f0 + fr[j] < n_frames) {
-                uint4 *o = reinterpret_cast<uint4 *>(pcm + (uint64_t)f0 * kFrame) + 2u * ((uint32_t)j * 64u + lane);
-                o[0] = o0;
-                o[1] = o1;
+            for (int j = 0; j < kLoadsPerChunk; ++j) {
+                lm0[j] = (uint32_t)__builtin_amdgcn_sbfe(am_lo, fr[j], 1) & 0x80808080u;
+                lm1[j] = (uint32_t)__builtin_amdgcn_sbfe(am_hi, fr[j], 1) & 0x80808080u;
             }
-        }
-        wave_lds_fence();
-        if (lane < (uint32_t)kChunkFrames) {
-            const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kPiecesPerFrame);   // 80 B rows, 16 B aligned
-            uint64_t s = 0;
-            uint32_t peak = 0, bsum = 0, fail = 0;
+            uint4 *pcm16 = STORE_PCM ? reinterpret_cast<uint4 *>(pcm + (uint64_t)f0 * kFrame) : nullptr;
+            const uint4 *nsrc = src16 + (s_load * (uint32_t)kStripEntries + lane);
+            const uint32_t nxt_pt = fetch_pt(s_load);
+            if (DIAG) d_b = now_cycles();
+            process_half<STORE_PCM>(lds, strip, X, lm0, pm, off, lane, pcm16, nsrc);
+            if (DIAG) d_c = now_cycles();
+            process_half<STORE_PCM>(lds, strip + kPiecesPerChunk, Y, lm1, pm, off, lane, pcm16 + 2 * kPiecesPerChunk, nsrc + kPiecesPerChunk);
+            if (DIAG) d_d = now_cycles();
+            if (has_next) k_next = grab();         // its LDS round trip hides under the frame fold below
+
+            wave_lds_fence();
+            {
+                const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kPiecesPerFrame);   // 80 B rows, 16 B aligned
+                uint64_t s = 0;
+                uint32_t peak = 0, bsum = 0, fail = 0;
 #pragma unroll
-            for (int i = 0; i < kPiecesPerFrame / 2; ++i) {
-                const uint4 v = row[i];
-                s += (uint64_t)v.x + (uint64_t)v.z;
-                peak = max(max(peak, v.y & 0x7FFFu), v.w & 0x7FFFu);
-                bsum += ((v.y >> 16) & 0x7FFFu) + ((v.w >> 16) & 0x7FFFu);
-                fail |= v.y | v.w;
-            }
-            const uint32_t fi = f0 + lane;
-            if (fi < n_frames) {
-                const uint64_t sumsq = s << 4;
+                for (int i = 0; i < kPiecesPerFrame / 2; ++i) {
+                    const uint4 v = row[i];
+                    s += (uint64_t)(v.x + v.z);                   // two 30-bit piece sums fit 32 bits
+                    peak = max(max(peak, v.y & 0x7FFFu), v.w & 0x7FFFu);
+                    bsum += ((v.y >> 16) & 0x7FFFu) + ((v.w >> 16) & 0x7FFFu);
+                    fail |= v.y | v.w;
+                }
                 uint32_t bm, fl;
-                *reinterpret_cast<uint4 *>(stats + fi) = pack_stats(sumsq, peak, bsum, (uint32_t)kFrame, my_alaw != 0u, (fail >> 31) == 0u, bm, fl);
+                st_stream(reinterpret_cast<uint4 *>(stats + (f0 + lane)), pack_stats160(s, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl));
                 if (AGG) {
-                    a_sumsq += sumsq; a_frames += 1u; a_sil += (fl & IGDSP_FLAG_SILENT) ? 1u : 0u;
+                    a_sumsq += s << 4; a_frames += 1u; a_sil += (fl & IGDSP_FLAG_SILENT) ? 1u : 0u;
                     a_clip += (fl & IGDSP_FLAG_CLIPPED) ? 1u : 0u; a_bm += bm; a_peak = max(a_peak, peak);
                 }
             }
+            wave_lds_fence();
+            if (DIAG) { d_iter += 1; d_setup += d_b - d_a; d_px += d_c - d_b; d_py += d_d - d_c; d_red += now_cycles() - d_d; }
+            if (!has_next) break;
+            sidx = s_next;
+            cur_pt = nxt_pt;
         }
-        wave_lds_fence();
-    };
-
-    // software pipeline: chunk k+1's five loads are in flight while chunk k is reduced.
-    // The last chunk is peeled so that NO load in the steady-state loop is conditional.
-    uint4 cur[kLoadsPerChunk];
-    uint32_t cur_pt;
-    uint32_t ck = wave_id;
-    fetch(cur, cur_pt, ck, c_base);
-    while (ck + total_waves < n_chunks) {
-        uint4 nxt[kLoadsPerChunk];
-        uint32_t nxt_pt;
-        uint32_t c_next = c_base + c_step;
-        if (c_next >= C) c_next -= C;
-        fetch(nxt, nxt_pt, ck + total_waves, c_next);
-        process(cur, cur_pt, ck);
-#pragma unroll
-        for (int j = 0; j < kLoadsPerChunk; ++j) cur[j] = nxt[j];
-        cur_pt = nxt_pt;
-        c_base = c_next;
-        ck += total_waves;
     }
-    process(cur, cur_pt, ck);
-
-    if (AGG && agg != nullptr)
-        agg_commit(agg, rank, a_sumsq, (uint64_t)a_frames * kFrame, a_frames, a_sil, a_clip, a_bm, a_peak);
+    if (DIAG && lane == 0 && diag != nullptr) {
+        uint64_t *o = diag + (uint64_t)(blockIdx.x * kWavesPerBlock + wave) * 12u;
+        o[0] = d_t0; o[1] = d_t1; o[2] = now_cycles(); o[3] = d_setup; o[4] = d_px; o[5] = d_iter; o[6] = d_py;
+        o[7] = __builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID, bits [3:0]
+        o[8] = d_rt0; o[9] = __builtin_amdgcn_s_memrealtime(); o[10] = d_red; o[11] = wave;
+    }
+    if (AGG && agg != nullptr)   // kernel-argument uniform: every thread of the block takes the same side
+        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kWavesPerBlock, a_sumsq, (uint64_t)a_frames * kFrame, a_frames,
+                         a_sil, a_clip, a_bm, a_peak);
 }
 
 // ============================================================================
@@ -703,24 +858,43 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
     const uint64_t n_frames64 = (uint64_t)C * F;
     if (n_frames64 == 0) return hipSuccess;
     const uint32_t n_frames = (uint32_t)n_frames64;
-    const bool chunk_ok = (n == (uint32_t)kFrame) && (len == nullptr) && (C >= (uint32_t)kChunkFrames) &&
+    const bool chunk_ok = (n == (uint32_t)kFrame) && (len == nullptr) &&
                           ((reinterpret_cast<uintptr_t>(payload) & 15u) == 0u) &&
                           (pcm == nullptr || (reinterpret_cast<uintptr_t>(pcm) & 15u) == 0u) &&
                           ((reinterpret_cast<uintptr_t>(stats) & 15u) == 0u);
-    if (variant != 1 && chunk_ok) {
-        const uint32_t n_chunks = (n_frames + kChunkFrames - 1) / kChunkFrames;
-        const uint32_t grid = blocks_for(n_chunks, kWavesPerBlock, (uint32_t)cfg.compute_units);
+    // tuned path takes the whole super-chunks (64 frames); the < 64 remaining frames, and every shape it
+    // does not cover, go through the general wave-per-frame kernel on the same stream.
+    uint32_t done = 0;
+    if (variant != 1 && chunk_ok && n_frames >= (uint32_t)kSuperFrames) {
+        const uint32_t n_super = n_frames / kSuperFrames;
+        done = n_super * kSuperFrames;
+        const uint32_t grid = blocks_for(n_super, kWavesPerBlock, (uint32_t)cfg.compute_units);
+        uint64_t *nodiag = nullptr;
         if (pcm) {
-            if (agg) hipLaunchKernelGGL((k_meter_chunk32<true, true>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, n_frames, stats, pcm, agg, rank);
-            else     hipLaunchKernelGGL((k_meter_chunk32<true, false>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, n_frames, stats, pcm, agg, rank);
+            if (agg) hipLaunchKernelGGL((k_meter_chunk64<true, true>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag);
+            else     hipLaunchKernelGGL((k_meter_chunk64<true, false>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag);
         } else {
-            if (agg) hipLaunchKernelGGL((k_meter_chunk32<false, true>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, n_frames, stats, pcm, agg, rank);
-            else     hipLaunchKernelGGL((k_meter_chunk32<false, false>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, n_frames, stats, pcm, agg, rank);
+            if (agg) hipLaunchKernelGGL((k_meter_chunk64<false, true>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag);
+            else     hipLaunchKernelGGL((k_meter_chunk64<false, false>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag);
         }
-    } else {
-        const uint32_t grid = blocks_for(n_frames, 4, (uint32_t)cfg.compute_units * 8u);
-        hipLaunchKernelGGL(k_meter_wave_per_frame, dim3(grid), dim3(256), 0, s, payload, codec, len, C, n_frames, n, stats, pcm, agg, rank);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
     }
+    if (done < n_frames) {
+        const uint32_t grid = blocks_for(n_frames - done, 4, (uint32_t)cfg.compute_units * 4u);
+        hipLaunchKernelGGL(k_meter_wave_per_frame, dim3(grid), dim3(256), 0, s, payload, codec, len, C, done, n_frames, n, stats, pcm, agg, rank);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_diag_chunk32(const LaunchCfg &cfg, const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F,
+                               igdsp_frame_stats *stats, uint64_t *diag, hipStream_t s)
+{
+    const uint32_t n_super = (C * F) / kSuperFrames;
+    const uint32_t n_frames = n_super * kSuperFrames;
+    const uint32_t grid = blocks_for(n_super, kWavesPerBlock, (uint32_t)cfg.compute_units);
+    hipLaunchKernelGGL((k_meter_chunk64<false, false, true>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, n_frames,
+                       stats, (int16_t *)nullptr, (igdsp_aggregate *)nullptr, 0u, diag);
     return hipGetLastError();
 }
 

@@ -12,7 +12,7 @@
  * Plain C types only; usable from C99 and C++11 (the reference builds with
  * CONFIG += c++11, iGate4xSoftphoneDSP.pro:2).  No torch / HIP types appear
  * here: device buffers are `void*`-compatible raw pointers, streams are an
- * opaque `void*` (a hipStream_t, or NULL for the context's own stream).
+ * opaque `void*` (a hipStream_t; NULL is HIP's legacy default stream).
  *
  * Error convention follows the reference (pj_status_t, PJ_SUCCESS == 0,
  * TransportAdapter.cpp:135-223): every entry returns int, 0 == success,
@@ -191,8 +191,8 @@ int igdsp_get_hold(igdsp_ctx *ctx, uint32_t channel, igdsp_chan_hold *out);
  * stats[f][c], pcm[f][c][n] i16.  n = samples_per_frame (1..256; 160 is the tuned
  * path).  d_len (optional, may be NULL) gives a per-frame valid length
  * len[f][c] <= n for ragged input; bytes past len are ignored; len 0 marks an
- * empty slot.  Work is enqueued on `stream` (a hipStream_t; NULL = the context's
- * stream) and NOT synchronised. */
+ * empty slot.  Work is enqueued on `stream` (a hipStream_t; NULL = the legacy
+ * default stream) and NOT synchronised. */
 
 /* a1+a3+a5+a7: decode + meter.  d_pcm may be NULL (meter-only, the headline).
  * d_agg (optional) is an igdsp_aggregate on the device that this launch ADDS

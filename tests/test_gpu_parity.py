@@ -361,7 +361,12 @@ def test_full_size_variants_agree(ctx, big):
     ctx.decode_meter(big["d_pl"], big["d_cd"], big["C"], big["F"], big["n"], d_st1, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     ctx.set_variant(0)
-    assert torch.equal(d_st1, big["d_st"])
+    a, b = gu.to_host(d_st1, capi.FRAME_STATS), gu.to_host(big["d_st"], capi.FRAME_STATS)
+    for f in ("sumsq", "peak", "byte_mean", "flags"):          # every integer field bit-identical
+        assert np.array_equal(a[f], b[f]), f
+    # rms: IEEE divide+sqrt (variant 1) vs multiply + v_sqrt_f32 (tuned path): within 4 ulp of each other,
+    # both inside the 1e-5 contract (checked against float64 in test_full_size_checksum_of_checksums)
+    assert np.all(np.abs(a["rms"].view(np.int32).astype(np.int64) - b["rms"].view(np.int32).astype(np.int64)) <= 4)
 
 
 def test_full_size_roundtrip_idempotence_config5(ctx, big, orc):
