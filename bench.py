@@ -166,9 +166,9 @@ def main():
     kern_med_ms = sorted(kern_ms)[len(kern_ms) // 2]
 
     # node-wide aggregate from the last launch (after the all-reduce every rank holds all peak slots)
-    last = aggs[(args.warmup + args.steps - 1) & 1].cpu().numpy().view(np.uint64)
-    node_rms = float(np.sqrt(float(last[0]) / max(float(last[1]), 1.0)))
-    node_peak = int(last[6:].max())
+    from igate4xsoftphonedsp_amd import dist as igdist
+
+    node = igdist.node_view(aggs[(args.warmup + args.steps - 1) & 1])
 
     samples_per_step_rank = C_ * F_ * n
     total_samples = samples_per_step_rank * world * args.steps
@@ -204,7 +204,7 @@ def main():
             "algorithmic_bytes_per_sample": round(bps, 5),
             "algorithmic_bytes_per_launch": int(samples_per_step_rank * bps),
         },
-        "aggregate": {"node_rms": round(node_rms, 3), "node_peak": node_peak, "samples": int(last[1])},
+        "aggregate": {"node_rms": round(node["rms"], 3), "node_peak": node["peak"], "samples": node["samples"]},
     }
 
     if args.stream_calib:

@@ -1,0 +1,125 @@
+// igdsp_host.h — C++11 host side above the C ABI: the reference's per-frame plugin interface,
+// re-created so the softphone's RTP depayloader drops onto the MI355X path unchanged.
+//
+// Names, argument meaning and error behaviour mirror (own implementation, nothing copied):
+//   struct tp_adapter                      TransportAdapter.h:40-93   (only the fields the hooks touch)
+//   transport_rtp_cb(user_data,pkt,size)   TransportAdapter.cpp:240-316
+//   transport_send_rtp(tp,pkt,size)        TransportAdapter.cpp:635-874 (level/probe part only)
+//   RoIP_ED137::setIncomingRTP / setOutgoingRTP / setIncomingED137Value   roip_ed137.cpp:6500-6587
+//   trx::IncomingRTP / OutgoingRTP slots   roip_ed137.h:741-750
+//   updateInputLevel(int percent)          roip_ed137.cpp:584-592 ; AudioMeter::onValueChanged audiometer.h:14
+// PJSIP types are replaced by plain ones (pj_status_t -> int, PJ_SUCCESS == 0, pj_ssize_t -> long).
+// No Qt is needed to build this file; a Qt build can forward `onValueChanged(int)` to its own signal.
+#ifndef IGDSP_HOST_H
+#define IGDSP_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "igdsp.h"
+
+#define SERVER 1      /* roip_ed137.h:107 — hooks only meter when inviteMode == SERVER */
+#define CLIENT 2
+
+// 20-byte ED-137 RTP header as the reference lays it out for little-endian targets
+// (ed137_rtp.h:22-48 with PJ_IS_LITTLE_ENDIAN, iGate4xSoftphoneDSP.pro:88): 12 B RTP, 4 B
+// extension header (profile 0x0167, length 1), 4 B ED-137 word (network order).
+#pragma pack(push, 1)
+struct custom_rtp_hdr {
+    uint8_t  cc : 4, x : 1, p : 1, v : 2;
+    uint8_t  pt : 7, m : 1;
+    uint16_t seq;
+    uint32_t ts;
+    uint32_t ssrc;
+    uint16_t profile_data;
+    uint16_t length;
+    uint32_t ed137;
+};
+#pragma pack(pop)
+static_assert(sizeof(custom_rtp_hdr) == 20, "ED-137 RTP header is 20 bytes");
+enum { IGDSP_RTP_HDR = 12 };                 /* sizeof(pjmedia_rtp_hdr), TransportAdapter.cpp:270 */
+
+struct tp_adapter {
+    void *stream_user_data;
+    void (*stream_rtp_cb)(void *user_data, void *pkt, long size);   // pjmedia stream callback (G.711 decode happened behind it)
+    int      radiostatus;                    // radio call => 20-byte header, else plain 12-byte RTP
+    int16_t  rtpFalse;                       // consecutive TX silence-probe hits (TransportAdapter.cpp:661-672)
+    int      callID;
+    uint32_t ed137_value;
+    uint32_t payloadsize;
+    uint8_t  pkt_buff[256];
+    size_t   bufSize;
+    uint8_t  payload_buff[256];
+    size_t   payload_bufSize;
+    uint8_t  send_pkt_buff[256];
+    uint8_t  tmp_payload_buf[256];
+    size_t   send_bufSize;
+    uint8_t  send_payload_buff[256];
+    size_t   send_payload_bufSize;
+    long long r2sPacket;                     // ms timestamp of the last packet (R2S watchdog input)
+    int      rtpAudio;
+    uint8_t  last_rx_pt, last_tx_pt;         // (ours) PT seen by the callback, handed to the shim
+};
+
+struct trx {                                 // roip_ed137.h:741-750 (level slots only)
+    int     call_id;
+    uint8_t OutgoingRTP, IncomingRTP;
+    // decoded-domain meter of the same frames (new; filled from igdsp_poll)
+    float    in_rms, out_rms;
+    uint16_t in_peak, out_peak, in_peak_hold, out_peak_hold;
+    int      in_percent, out_percent;        // AudioMeter scale: int(float(v*100.0/30000.0))
+    uint8_t  in_flags, out_flags;
+};
+
+class RoIP_ED137 {
+public:
+    // Unlike the reference singleton (roip_ed137.cpp:192) the instance owns an igdsp context; device < 0
+    // is rejected — there is no CPU metering path.
+    static RoIP_ED137 *create(int device, uint32_t max_calls);
+    static RoIP_ED137 *instance();           // the last created instance (the hooks' entry point)
+    ~RoIP_ED137();
+
+    int inviteMode;
+    bool referenceTxQuirk;                   // true: TX level over the first n bytes of the WHOLE packet, as
+                                             // setOutgoingRTP does (tmp_payload_buf = header+payload, roip_ed137.cpp:6505)
+    trx *radio[4];                           // trx1->radio1, trx1->radio2, trx2->radio1, trx2->radio2
+
+    void setIncomingRTP(tp_adapter *adapter);
+    void setOutgoingRTP(tp_adapter *adapter);
+    void setIncomingED137Value(uint32_t ed137_value, int acc_id);
+    uint32_t ed137Events;                    // times checkEvents() would have been entered (roip_ed137.cpp:6537-6540)
+
+    // Owner-thread tick (the reference polls on a 40 ms QTimer, roip_ed137.cpp:1756): flush staged frames to
+    // the GPU, then fill trx slots exactly where the reference's if-chain would (roip_ed137.cpp:6519-6534, 6570-6585).
+    int tick(uint32_t *frames_done);
+    void (*onValueChanged)(int call_id, int is_tx, int percent);   // AudioMeter::onValueChanged stand-in
+    igdsp_ctx *ctx() { return ctx_; }
+    int bindRadio(int slot, int call_id);    // slot 0..3; maps RX to channel 2*slot, TX to 2*slot+1
+
+private:
+    RoIP_ED137();
+    igdsp_ctx *ctx_;
+};
+
+extern "C" {
+// pjmedia-facing callbacks with the reference's signatures
+void transport_rtp_cb(void *user_data, void *pkt, long size);
+int  transport_send_rtp(tp_adapter *tp, const void *pkt, size_t size);
+int  decodeRtp(void *pkt, custom_rtp_hdr **hdr);
+
+// flat C handles for tests / non-C++ hosts
+void       *igdsp_host_create(int device, uint32_t max_calls);
+void        igdsp_host_destroy(void *h);
+tp_adapter *igdsp_host_adapter_new(int call_id, int radiostatus);
+void        igdsp_host_adapter_free(tp_adapter *a);
+int         igdsp_host_bind_radio(void *h, int slot, int call_id);
+int         igdsp_host_set_mode(void *h, int invite_mode, int reference_tx_quirk);
+int         igdsp_host_tick(void *h, uint32_t *frames_done);
+int         igdsp_host_get_trx(void *h, int slot, trx *out);
+uint32_t    igdsp_host_ed137_events(void *h);
+// WavWriter-compatible recorder (WavWriter.cpp:41-156): writeRTPWav signature, same bytes on disk
+void *igdsp_wav_start(const char *path, int rate);
+int   igdsp_wav_writeRTPWav(void *w, const char *pktbuf, const char *payloadbuf, unsigned pktlen, unsigned payloadlen);
+int   igdsp_wav_stop(void *w);
+}
+#endif

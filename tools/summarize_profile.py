@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_<tag>/ (written by tools/profile.sh on the GPU box) into the tracked
+profiles/<tag>_* files and profiles/pmc_traffic.json (read by bench.py for roofline.traffic)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+KEY = "k_meter_chunk64"
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(src, pattern), recursive=True)
+    return g[0] if g else None
+
+
+lines = [f"# rocprofv3 summary — {tag} — `python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline` (1x MI355X)", ""]
+ks = one("stats/**/*kernel_stats.csv")
+if ks:
+    shutil.copy(ks, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    rows = list(csv.DictReader(open(ks)))
+    lines += ["## --kernel-trace --stats (no counters in this pass)", "", "| kernel | calls | total ns | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|---|"]
+    for r in rows:
+        lines.append(f"| `{r['Name'][:90]}` | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {r['Percentage']} |")
+    lines.append("")
+
+
+def counters(sub):
+    f = one(f"{sub}/**/*counter_collection.csv")
+    agg = collections.defaultdict(list)
+    if f:
+        for r in csv.DictReader(open(f)):
+            if KEY in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}, f
+
+
+def durations(sub):
+    f = one(f"{sub}/**/*kernel_trace.csv")
+    d = []
+    if f:
+        for r in csv.DictReader(open(f)):
+            if KEY in r["Kernel_Name"]:
+                d.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return d
+
+
+fetch, ff = counters("fetch")
+write, wf = counters("write")
+traffic = None
+if "FETCH_SIZE" in fetch and "WRITE_SIZE" in write:
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly
+    # half of the bytes of a wide (16 B/lane) coalesced streaming read -> double it; WRITE_SIZE is exact
+    # for 16 B/lane streaming stores.  Collected in two separate --pmc passes.
+    rd = 2.0 * fetch["FETCH_SIZE"] * 1024.0
+    wr = write["WRITE_SIZE"] * 1024.0
+    traffic = rd + wr
+    alg = 65536 * 128 * 160 * (160 + 1 + 16) / 160.0
+    lines += ["## HBM traffic per launch of `k_meter_chunk64` (separate --pmc passes)", "",
+              f"* FETCH_SIZE = {fetch['FETCH_SIZE']:.0f} KiB raw -> x2 (gfx950 wide-stream correction) = {rd / 1e6:.1f} MB read",
+              f"* WRITE_SIZE = {write['WRITE_SIZE']:.0f} KiB = {wr / 1e6:.1f} MB written",
+              f"* total {traffic / 1e6:.1f} MB vs algorithmic {alg / 1e6:.1f} MB (ratio {traffic / alg:.3f})", ""]
+    json.dump({"kernel": KEY, "channels": 65536, "frames": 128, "mode": "meter", "hbm_bytes_per_launch": int(traffic),
+               "read_bytes": int(rd), "write_bytes": int(wr),
+               "source": f"profiles/{tag}_pmc_fetch.csv + {tag}_pmc_write.csv; FETCH_SIZE x2 x1024 + WRITE_SIZE x1024 (MI355X_MICROARCH.md HBM section)"},
+              open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    shutil.copy(ff, os.path.join(dst, f"{tag}_pmc_fetch.csv"))
+    shutil.copy(wf, os.path.join(dst, f"{tag}_pmc_write.csv"))
+for sub in ("sq", "sq2"):
+    c, f = counters(sub)
+    if c:
+        d = durations(sub)
+        lines += [f"## SQ counters, pass `{sub}` (avg per dispatch of `{KEY}`; kernel {sum(d) / max(len(d), 1) / 1e3:.1f} us under the profiler)", ""]
+        lines += [f"* {k} = {v:.4g}" for k, v in sorted(c.items())]
+        lines.append("")
+        shutil.copy(f, os.path.join(dst, f"{tag}_pmc_{sub}.csv"))
+d = durations("stats")
+if d:
+    lines += [f"kernel-trace durations of `{KEY}` in the stats pass: n={len(d)} avg {sum(d) / len(d) / 1e3:.1f} us min {min(d) / 1e3:.1f} max {max(d) / 1e3:.1f}", ""]
+bj = os.path.join(src, "bench_unprofiled.json")
+if os.path.exists(bj):
+    txt = [l for l in open(bj).read().splitlines() if l.startswith("{")]
+    if txt:
+        shutil.copy(bj, os.path.join(dst, f"{tag}_bench_unprofiled.json"))
+        j = json.loads(txt[-1])
+        lines += ["## un-profiled bench line of the same build", "", "```json", json.dumps(j, indent=1), "```", ""]
+open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines))
+print("\n".join(lines))
