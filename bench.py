@@ -30,7 +30,8 @@ if ROOT not in sys.path:
 
 N_SAMPLES = 160
 # algorithmic bytes per sample, meter-only = (160 payload + 1 codec id + 16 result) / 160
-BYTES_PER_SAMPLE = {"meter": (160 + 1 + 16) / 160.0, "store": (160 + 1 + 16 + 320) / 160.0}
+BYTES_PER_SAMPLE = {"meter": (160 + 1 + 16) / 160.0, "store": (160 + 1 + 16 + 320) / 160.0,
+                    "roundtrip": (160 + 1 + 16 + 160) / 160.0}   # config #5: read 1 + write 1 + record
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -41,10 +42,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels", type=int, default=65536, help="channels PER GPU")
     ap.add_argument("--frames", type=int, default=128)
-    ap.add_argument("--mode", choices=["meter", "store"], default="meter")
+    ap.add_argument("--mode", choices=["meter", "store", "roundtrip"], default="meter")
     ap.add_argument("--variant", type=int, default=0, help="0 tuned default, 1 wave-per-frame, 2 chunk32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on GPUs; gloo only to rehearse the N>1 path on one GPU")
+    ap.add_argument("--one-gpu-rehearsal", action="store_true", help="all ranks use cuda:0 (with --backend gloo)")
     ap.add_argument("--no-agg", action="store_true", help="experiment: skip the launch aggregate (N=1 only)")
     ap.add_argument("--stream-calib", action="store_true", help="also time the read-only stream kernel")
     return ap.parse_args()
@@ -96,9 +99,14 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the igdsp kernels have no CPU fallback")
+    if args.one_gpu_rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     if world > capi.AGG_MAX_RANKS:
         raise SystemExit("aggregate vector has 8 peak slots")
 
@@ -119,6 +127,12 @@ def main():
         first = (f * C_total + rank * C_) * n
         ctx.gen_uniform(d_pl[f], C_ * n, first_byte=first, stream=hs)
     d_cd = torch.zeros((C_,), dtype=torch.uint8, device="cuda")           # mu-law (RTP PT 0) everywhere
+    d_out = d_hold = None
+    if args.mode == "roundtrip":                                          # BASELINE configs[4]: mixed A-law / mu-law
+        d_cd[1::2] = 8
+        d_out = torch.empty_like(d_pl)
+        d_hold = torch.zeros((C_ * 4,), dtype=torch.int64, device="cuda")
+        ctx.hold_reset(d_hold, C_, stream=hs)
     d_st = torch.zeros((F_ * C_ * 2,), dtype=torch.int64, device="cuda")   # igdsp_frame_stats[F][C]
     d_pcm = torch.empty((F_, C_, n), dtype=torch.int16, device="cuda") if args.mode == "store" else None
     aggs = [torch.zeros((capi.AGG_WORDS,), dtype=torch.int64, device="cuda") for _ in range(2)]
@@ -132,7 +146,10 @@ def main():
         aggs[b].zero_()
         if timer is not None:
             timer.start(hs)
-        ctx.decode_meter(d_pl, d_cd, C_, F_, n, d_st, pcm=d_pcm, agg=None if args.no_agg else aggs[b], rank=rank, stream=hs)
+        if args.mode == "roundtrip":
+            ctx.roundtrip_peakhold(d_pl, d_cd, C_, F_, n, d_out, d_st, d_hold, stream=hs)
+        else:
+            ctx.decode_meter(d_pl, d_cd, C_, F_, n, d_st, pcm=d_pcm, agg=None if args.no_agg else aggs[b], rank=rank, stream=hs)
         if timer is not None:
             timer.stop(hs)
         if world > 1:                              # node-wide sum / peak: one 112-byte all-reduce per launch, side stream
@@ -175,7 +192,7 @@ def main():
     value = total_samples / dt / 1e6
     bps = BYTES_PER_SAMPLE[args.mode]
     achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9
-    kernel_name = "k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64"
+    kernel_name = "k_roundtrip_chunk32" if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64")
 
     out = {
         "metric": "Msamples/s G.711 decode+RMS, 65536ch@8kHz; %HBM roofline at 1/2/4/8 GPU",

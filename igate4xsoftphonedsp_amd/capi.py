@@ -39,6 +39,8 @@ CHAN_HOLD = np.dtype(
      ("level_max", "u1"), ("level_min", "u1"), ("n_silent", "<u4"), ("n_clipped", "<u4")],
     align=True,
 )
+RTP_INFO = np.dtype([("ed137", "<u4"), ("payload_len", "<u2"), ("pt", "u1"), ("flags", "u1")], align=True)
+RTP_V2, RTP_X, RTP_MARKER, RTP_ED137_OK, RTP_KEEPALIVE, RTP_METERED, RTP_RUNT, RTP_OVERSIZE = 1, 2, 4, 8, 16, 32, 64, 128
 AGGREGATE = np.dtype(
     [("sumsq", "<u8"), ("samples", "<u8"), ("frames", "<u8"), ("n_silent", "<u8"), ("n_clipped", "<u8"),
      ("byte_mean_sum", "<u8"), ("peak_slot", "<u8", (AGG_MAX_RANKS,))]
@@ -78,6 +80,7 @@ PROTOTYPES = [
     ("igdsp_hold_update", _int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     ("igdsp_hold_reset", _int, [_vp, _vp, _u32, _vp, _vp]),
     ("igdsp_agg_reset", _int, [_vp, _vp, _vp]),
+    ("igdsp_depayload", _int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     ("igdsp_gen_uniform", _int, [_vp, _vp, _u64, _u64, _u64, _vp]),
     ("igdsp_dev_alloc", _int, [_vp, C.POINTER(_vp), C.c_size_t]),
     ("igdsp_dev_free", _int, [_vp, _vp]),
@@ -230,6 +233,10 @@ class Context:
 
     def agg_reset(self, agg, stream=None):
         self._ck(self.L.igdsp_agg_reset(self.h, _ptr(agg), stream), "igdsp_agg_reset")
+
+    def depayload(self, packets, sizes, radio, C_, F_, stride, n, payload_out, len_out, info_out, stream=None):
+        self._ck(self.L.igdsp_depayload(self.h, _ptr(packets), _ptr(sizes), _ptr(radio), C_, F_, stride, n, _ptr(payload_out),
+                                        _ptr(len_out), _ptr(info_out), stream), "igdsp_depayload")
 
     def gen_uniform(self, out, n_bytes, seed=0x20241218, first_byte=0, stream=None):
         self._ck(self.L.igdsp_gen_uniform(self.h, _ptr(out), n_bytes, seed, first_byte, stream), "igdsp_gen_uniform")

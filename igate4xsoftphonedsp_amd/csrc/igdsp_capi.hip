@@ -384,6 +384,21 @@ int igdsp_agg_reset(igdsp_ctx *ctx, igdsp_aggregate *d_agg, void *stream)
     return IGDSP_OK;
 }
 
+int igdsp_depayload(igdsp_ctx *ctx, const uint8_t *d_packets, const uint16_t *d_sizes, const uint8_t *d_radio, uint32_t C,
+                    uint32_t F, uint32_t pkt_stride, uint32_t n, uint8_t *d_payload_out, uint16_t *d_len_out,
+                    igdsp_rtp_info *d_info_out, void *stream)
+{
+    if (!ctx) return IGDSP_EINVAL;
+    if ((uint64_t)C * F == 0) return IGDSP_OK;
+    if (!d_packets || !d_radio || !d_payload_out || !d_len_out || !d_info_out) return IGDSP_EINVAL;
+    if (int rc = check_shape(C, F, n)) return rc;
+    // slots hold at least a 20-byte header, are dword-granular (so header words and payload dwords are aligned)
+    if (pkt_stride < 20u || (pkt_stride & 3u) || pkt_stride > 2048u || (reinterpret_cast<uintptr_t>(d_packets) & 3u)) return IGDSP_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_depayload(cfg_of(ctx), d_packets, d_sizes, d_radio, C, F, pkt_stride, n, d_payload_out, d_len_out, d_info_out, pick(ctx, stream)));
+    return IGDSP_OK;
+}
+
 int igdsp_gen_uniform(igdsp_ctx *ctx, uint8_t *d_out, uint64_t n_bytes, uint64_t seed, uint64_t first_byte, void *stream)
 {
     if (!ctx || (!d_out && n_bytes)) return IGDSP_EINVAL;

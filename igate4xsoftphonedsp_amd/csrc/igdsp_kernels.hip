@@ -786,6 +786,94 @@ __global__ __launch_bounds__(256) void k_hold_reset(igdsp_chan_hold *__restrict_
 }
 
 // ============================================================================
+// SURVEY 8(f) rank 1 — ED-137 RTP depayload + gather (transport_rtp_cb's header parse and payload
+// copy, TransportAdapter.cpp:240-292, batched).  One lane per 16-byte piece of the DENSE output:
+// writes are full coalesced dwordx4; reads come from pkt + header (4-byte aligned: header 12 or 20,
+// slot stride % 4 == 0) as four dwords.  Lane q == 0 of a frame also parses the header and emits
+// len / info.  Needs n % 16 == 0; other n use the byte kernel below.
+// ============================================================================
+struct FrameHdr { uint32_t len; igdsp_rtp_info info; };
+
+__device__ __forceinline__ FrameHdr parse_rtp(const uint8_t *pkt, uint32_t size, uint32_t hdr, bool radio, uint32_t n)
+{
+    FrameHdr r;
+    r.len = 0; r.info.ed137 = 0; r.info.payload_len = 0; r.info.pt = 0; r.info.flags = 0;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(pkt);
+    if (size < hdr) {
+        r.info.flags = IGDSP_RTP_RUNT;
+        if (size >= 2u) r.info.pt = (uint8_t)((w[0] >> 8) & 0x7Fu);
+        return r;
+    }
+    const uint32_t w0 = w[0];
+    const uint32_t pt = (w0 >> 8) & 0x7Fu;
+    uint32_t fl = (((w0 >> 6) & 3u) == 2u ? IGDSP_RTP_V2 : 0u) | ((w0 & 0x10u) ? IGDSP_RTP_X : 0u) | ((w0 & 0x8000u) ? IGDSP_RTP_MARKER : 0u);
+    if (radio) {
+        const uint32_t w3 = w[3], w4 = w[4];
+        if (pt == 8u || pt == 0u || pt == 18u || pt == 123u) r.info.ed137 = __builtin_bswap32(w4);   // ntohl
+        if ((w0 & 0x10u) && w3 == 0x01006701u) fl |= IGDSP_RTP_ED137_OK;                               // bytes 01 67 00 01
+    }
+    if (pt == 123u) fl |= IGDSP_RTP_KEEPALIVE;
+    const uint32_t pl = size - hdr;
+    if (pl > n) fl |= IGDSP_RTP_OVERSIZE;
+    else if ((pt == 0u || pt == 8u) && pl > 0u) { fl |= IGDSP_RTP_METERED; r.len = pl; }
+    r.info.pt = (uint8_t)pt; r.info.payload_len = (uint16_t)pl; r.info.flags = (uint8_t)fl;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_depayload16(const uint8_t *__restrict__ packets, const uint16_t *__restrict__ sizes,
+                                                     const uint8_t *__restrict__ radio, uint32_t C, uint32_t n_frames,
+                                                     uint32_t stride, uint32_t n, uint8_t *__restrict__ payload,
+                                                     uint16_t *__restrict__ len, igdsp_rtp_info *__restrict__ info)
+{
+    const uint32_t ppf = n >> 4;                                   // pieces per frame
+    const uint64_t n_pieces = (uint64_t)n_frames * ppf;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pieces; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t fi = (uint32_t)(p / ppf), q = (uint32_t)(p - (uint64_t)fi * ppf);
+        const uint32_t c = fi % C;
+        const bool rad = radio[c] != 0;
+        const uint32_t hdr = rad ? 20u : 12u;
+        const uint8_t *pkt = packets + (uint64_t)fi * stride;
+        const uint32_t size = min(sizes ? (uint32_t)sizes[fi] : stride, stride);
+        const FrameHdr h = parse_rtp(pkt, size, hdr, rad, n);
+        if (q == 0u) { len[fi] = (uint16_t)h.len; info[fi] = h.info; }
+        const uint32_t b0 = q * 16u;
+        uint32_t v[4] = {0u, 0u, 0u, 0u};
+        if (h.len > b0) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(pkt + hdr + b0);
+            const uint32_t nb = min(h.len - b0, 16u);
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k)
+                if (nb > 4u * k) {                                  // the dword may extend past the packet's size but never past its slot
+                    uint32_t x = (hdr + b0 + 4u * k + 4u <= stride) ? src[k] : 0u;
+                    const uint32_t keep = nb - 4u * k;
+                    if (keep < 4u) x &= (1u << (8u * keep)) - 1u;
+                    v[k] = x;
+                }
+        }
+        reinterpret_cast<uint4 *>(payload)[p] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_depayload_bytes(const uint8_t *__restrict__ packets, const uint16_t *__restrict__ sizes,
+                                                         const uint8_t *__restrict__ radio, uint32_t C, uint32_t n_frames,
+                                                         uint32_t stride, uint32_t n, uint8_t *__restrict__ payload,
+                                                         uint16_t *__restrict__ len, igdsp_rtp_info *__restrict__ info)
+{
+    // one wavefront per frame, any n and any (4-byte aligned) stride
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t fi = blockIdx.x * 4u + wave; fi < n_frames; fi += gridDim.x * 4u) {
+        const uint32_t c = fi % C;
+        const bool rad = radio[c] != 0;
+        const uint32_t hdr = rad ? 20u : 12u;
+        const uint8_t *pkt = packets + (uint64_t)fi * stride;
+        const uint32_t size = min(sizes ? (uint32_t)sizes[fi] : stride, stride);
+        const FrameHdr h = parse_rtp(pkt, size, hdr, rad, n);
+        if (lane == 0u) { len[fi] = (uint16_t)h.len; info[fi] = h.info; }
+        for (uint32_t i = lane; i < n; i += 64u) payload[(uint64_t)fi * n + i] = (i < h.len) ? pkt[hdr + i] : (uint8_t)0;
+    }
+}
+
+// ============================================================================
 // Synthetic D-uniform generator: 8 bytes per splitmix64 word.
 // ============================================================================
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
@@ -943,6 +1031,22 @@ hipError_t launch_hold_reset(igdsp_chan_hold *hold, uint32_t C, const uint8_t *m
 {
     if (C == 0) return hipSuccess;
     hipLaunchKernelGGL(k_hold_reset, dim3((C + 255) / 256), dim3(256), 0, s, hold, C, mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_depayload(const LaunchCfg &cfg, const uint8_t *packets, const uint16_t *sizes, const uint8_t *radio,
+                            uint32_t C, uint32_t F, uint32_t stride, uint32_t n, uint8_t *payload, uint16_t *len,
+                            igdsp_rtp_info *info, hipStream_t s)
+{
+    const uint32_t n_frames = C * F;
+    if (n_frames == 0) return hipSuccess;
+    const uint32_t cap = (uint32_t)cfg.compute_units * 8u;
+    if ((n & 15u) == 0u && (reinterpret_cast<uintptr_t>(payload) & 15u) == 0u) {
+        const uint64_t pieces = (uint64_t)n_frames * (n >> 4);
+        hipLaunchKernelGGL(k_depayload16, dim3(blocks_for(pieces, 256, cap)), dim3(256), 0, s, packets, sizes, radio, C, n_frames, stride, n, payload, len, info);
+    } else {
+        hipLaunchKernelGGL(k_depayload_bytes, dim3(blocks_for(n_frames, 4, cap)), dim3(256), 0, s, packets, sizes, radio, C, n_frames, stride, n, payload, len, info);
+    }
     return hipGetLastError();
 }
 

@@ -228,6 +228,41 @@ int igdsp_hold_reset(igdsp_ctx *ctx, igdsp_chan_hold *d_hold, uint32_t n_channel
 
 int igdsp_agg_reset(igdsp_ctx *ctx, igdsp_aggregate *d_agg, void *stream);
 
+/* ---- ED-137 RTP depayload + gather on the device ------------------
+ * The step BEFORE the path: transport_rtp_cb's header parse and payload copy
+ * (TransportAdapter.cpp:240-292; header layout ed137_rtp.h:22-48), batched.
+ * Input  : packets[f][c][pkt_stride] raw RTP packets as received (slot of pkt_stride bytes,
+ *          pkt_stride % 4 == 0), sizes[f][c] = received size (NULL: every packet fills its slot),
+ *          radio[c] != 0 => 20-byte ED-137 header (12 B RTP + ext hdr 0x0167/len 1 + ED-137 word),
+ *          else plain 12-byte RTP (TransportAdapter.cpp:270,279).
+ * Output : payload[f][c][n] dense (bytes past the payload length zeroed), len[f][c] = metered payload
+ *          length (0 for PT 123 keep-alives, non-G.711 PTs, runts, and oversize packets — the
+ *          reference drops payloads it cannot buffer, TransportAdapter.cpp:286-291), info[f][c].
+ * `len` feeds igdsp_decode_meter's d_len directly. */
+typedef struct igdsp_rtp_info {
+    uint32_t ed137;        /* ntohl(ED-137 word), 0 on non-radio calls (get_ed137_value, TransportAdapter.cpp:337-346) */
+    uint16_t payload_len;  /* size - header, before any clamp (what transport_rtp_cb stores in payload_bufSize)       */
+    uint8_t  pt;           /* RTP payload type (7 bits)                                                              */
+    uint8_t  flags;        /* IGDSP_RTP_*                                                                            */
+} igdsp_rtp_info;
+#define IGDSP_RTP_V2        0x01  /* version field == 2                                   */
+#define IGDSP_RTP_X         0x02  /* header-extension bit                                 */
+#define IGDSP_RTP_MARKER    0x04
+#define IGDSP_RTP_ED137_OK  0x08  /* radio call, X set, profile 0x0167, length 1          */
+#define IGDSP_RTP_KEEPALIVE 0x10  /* PT 123 (R2S): never metered                          */
+#define IGDSP_RTP_METERED   0x20  /* PT 0 or 8 with a usable payload: len[f][c] > 0       */
+#define IGDSP_RTP_RUNT      0x40  /* size < header                                        */
+#define IGDSP_RTP_OVERSIZE  0x80  /* payload longer than n: dropped                       */
+/* ED-137 word fields, masks as the reference extracts them (Functions.cpp:1018,1045,1136,1148) */
+#define IGDSP_ED137_PTT_TYPE(v) (((v) & 0xe0000000u) >> 29)
+#define IGDSP_ED137_SQU(v)      (((v) & 0x10000000u) >> 28)
+#define IGDSP_ED137_PTT_ID(v)   (((v) & 0x0fc00000u) >> 22)
+#define IGDSP_ED137_BSS(v)      (((v) & 0x000000f8u) >> 3)
+
+int igdsp_depayload(igdsp_ctx *ctx, const uint8_t *d_packets, const uint16_t *d_sizes, const uint8_t *d_radio,
+                    uint32_t n_channels, uint32_t n_frames, uint32_t pkt_stride, uint32_t samples_per_frame,
+                    uint8_t *d_payload_out, uint16_t *d_len_out, igdsp_rtp_info *d_info_out, void *stream);
+
 /* ---- synthetic input generators (device side; SURVEY 8(d) definitions) ---------
  * D-uniform: byte k of global byte index g is
  *   (splitmix64(seed + (g>>3)) >> (8*(g&7))) & 0xFF,  g = first_byte + k

@@ -239,6 +239,52 @@ void orc_roundtrip_peakhold(const uint8_t *payload, const uint8_t *codec, uint32
 }
 
 /* ------------------------------------------------------------------------- */
+/* transport_rtp_cb (TransportAdapter.cpp:240-292): the header is the first    */
+/* 12 bytes (plain SIP) or 20 bytes (radio: custom_rtp_hdr, ed137_rtp.h:22-48) */
+/* of the packet; payloadlen = size - header; PT is the low 7 bits of byte 1;  */
+/* the ED-137 word is bytes 16..19 in network order (get_ed137_value does      */
+/* ntohl, :337-346) and is only taken when pt is 8, 0, 18 or 123 (:252).       */
+/* pt == 123 is a keep-alive: never handed to setIncomingRTP (:299,308).       */
+/* ------------------------------------------------------------------------- */
+void orc_depayload(const uint8_t *packets, const uint16_t *sizes, const uint8_t *radio, uint32_t C, uint32_t F,
+                   uint32_t stride, uint32_t n, uint8_t *payload, uint16_t *len, orc_rtp_info *info)
+{
+    for (uint32_t f = 0; f < F; ++f)
+        for (uint32_t c = 0; c < C; ++c) {
+            size_t fi = (size_t)f * C + c;
+            const uint8_t *pkt = packets + fi * stride;
+            uint32_t size = sizes ? sizes[fi] : stride;
+            if (size > stride) size = stride;
+            uint32_t hdr = radio[c] ? 20u : 12u;
+            orc_rtp_info in; memset(&in, 0, sizeof in);
+            uint8_t *out = payload + fi * n;
+            memset(out, 0, n);
+            len[fi] = 0;
+            if (size < hdr) { in.flags = 0x40; if (size >= 2) in.pt = pkt[1] & 0x7F; info[fi] = in; continue; }
+            unsigned pt = pkt[1] & 0x7Fu;
+            in.pt = (uint8_t)pt;
+            in.payload_len = (uint16_t)(size - hdr);
+            if ((pkt[0] >> 6) == 2) in.flags |= 0x01;
+            if (pkt[0] & 0x10) in.flags |= 0x02;
+            if (pkt[1] & 0x80) in.flags |= 0x04;
+            if (radio[c]) {
+                if (pt == 8 || pt == 0 || pt == 18 || pt == 123)
+                    in.ed137 = ((uint32_t)pkt[16] << 24) | ((uint32_t)pkt[17] << 16) | ((uint32_t)pkt[18] << 8) | pkt[19];
+                if ((pkt[0] & 0x10) && pkt[12] == 0x01 && pkt[13] == 0x67 && pkt[14] == 0x00 && pkt[15] == 0x01) in.flags |= 0x08;
+            }
+            if (pt == 123) in.flags |= 0x10;
+            uint32_t pl = size - hdr;
+            if (pl > n) in.flags |= 0x80;
+            else if ((pt == 0 || pt == 8) && pl > 0) {
+                in.flags |= 0x20;
+                memcpy(out, pkt + hdr, pl);
+                len[fi] = (uint16_t)pl;
+            }
+            info[fi] = in;
+        }
+}
+
+/* ------------------------------------------------------------------------- */
 uint64_t orc_splitmix64(uint64_t x)
 {
     uint64_t z = x + 0x9E3779B97F4A7C15ull;

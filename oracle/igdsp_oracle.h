@@ -67,6 +67,11 @@ void orc_roundtrip_peakhold(const uint8_t *payload, const uint8_t *codec, uint32
                             uint8_t *out, orc_frame_stats *stats, orc_chan_hold *hold,
                             const uint8_t *gate, int variant);
 
+/* TransportAdapter.cpp:240-292 restated: header parse + payload copy, batched */
+typedef struct { uint32_t ed137; uint16_t payload_len; uint8_t pt; uint8_t flags; } orc_rtp_info;
+void orc_depayload(const uint8_t *packets, const uint16_t *sizes, const uint8_t *radio, uint32_t C, uint32_t F,
+                   uint32_t stride, uint32_t n, uint8_t *payload, uint16_t *len, orc_rtp_info *info);
+
 /* synthetic data */
 uint64_t orc_splitmix64(uint64_t x);
 void orc_gen_uniform(uint8_t *out, uint64_t n_bytes, uint64_t seed, uint64_t first_byte);

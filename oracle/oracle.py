@@ -38,6 +38,8 @@ AGGREGATE = np.dtype(
 )
 assert FRAME_STATS.itemsize == 16 and CHAN_HOLD.itemsize == 32 and AGGREGATE.itemsize == 112
 
+RTP_INFO = np.dtype([("ed137", "<u4"), ("payload_len", "<u2"), ("pt", "u1"), ("flags", "u1")], align=True)
+assert RTP_INFO.itemsize == 8
 FLAG_SILENT, FLAG_PROBE_D5, FLAG_CLIPPED, FLAG_EMPTY = 1, 2, 4, 8
 ENC_SUN16, ENC_G191 = 0, 1
 SEED = 0x20241218
@@ -79,6 +81,8 @@ def lib() -> C.CDLL:
         L.orc_hold_update.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
         L.orc_roundtrip_peakhold.restype = None
         L.orc_roundtrip_peakhold.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_int]
+        L.orc_depayload.restype = None
+        L.orc_depayload.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
         L.orc_splitmix64.restype = C.c_uint64; L.orc_splitmix64.argtypes = [C.c_uint64]
         L.orc_gen_uniform.restype = None; L.orc_gen_uniform.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64]
         L.orc_gen_speech.restype = None
@@ -180,6 +184,20 @@ def roundtrip_peakhold(payload, codec, hold, gate=None, variant=ENC_SUN16):
         gate = np.ascontiguousarray(gate, dtype=np.uint8)
     lib().orc_roundtrip_peakhold(_p(payload), _p(codec), C_, F_, n, _p(out), _p(stats), _p(hold), _p(gate), variant)
     return out, stats, hold
+
+
+def depayload(packets, sizes, radio, n=160):
+    """packets [F][C][stride] u8 -> (payload [F][C][n], len [F][C] u16, info [F][C])."""
+    packets = np.ascontiguousarray(packets, dtype=np.uint8)
+    F_, C_, stride = packets.shape
+    radio = np.ascontiguousarray(radio, dtype=np.uint8)
+    if sizes is not None:
+        sizes = np.ascontiguousarray(sizes, dtype="<u2")
+    payload = np.zeros((F_, C_, n), np.uint8)
+    ln = np.zeros((F_, C_), "<u2")
+    info = np.zeros((F_, C_), RTP_INFO)
+    lib().orc_depayload(_p(packets), _p(sizes), _p(radio), C_, F_, stride, n, _p(payload), _p(ln), _p(info))
+    return payload, ln, info
 
 
 def byte_mean(buf: bytes | np.ndarray, signed_char=False) -> int:

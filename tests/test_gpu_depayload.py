@@ -1,0 +1,139 @@
+"""-m gpu: SURVEY 8(f) rank 1 — ED-137 RTP depayload + gather on the device, against the oracle's
+restatement of transport_rtp_cb (TransportAdapter.cpp:240-292) AND against the C++ host mirror's
+own transport_rtp_cb fed the same packets (two independent implementations)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from igate4xsoftphonedsp_amd import capi  # noqa: E402
+from tests import gpu_util as gu  # noqa: E402
+from tests import host_util as hu  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(device=0, max_channels=64)
+    yield c
+    c.close()
+
+
+def _make_packets(orc, C_, F_, stride, n, seed=1):
+    rng = np.random.default_rng(seed)
+    radio = (np.arange(C_) % 3 != 0).astype(np.uint8)
+    pk = orc.gen_uniform(F_ * C_ * stride, seed=seed).reshape(F_, C_, stride).copy()   # garbage beyond each packet
+    sizes = np.zeros((F_, C_), np.uint16)
+    for f in range(F_):
+        for c in range(C_):
+            hdr = 20 if radio[c] else 12
+            kind = rng.integers(0, 12)
+            pt = [0, 8, 0, 8, 0, 8, 123, 18, 96, 0, 8, 0][kind]
+            plen = [n, n, n, n, 24, n - 1, 0, 20, n, n + 4, 0, 1][kind]
+            size = hdr + plen
+            if kind == 11 and rng.integers(0, 2):
+                size = int(rng.integers(0, hdr))                          # runt
+            size = min(size, stride)
+            pkt = bytearray(hu.rtp_packet(pt, f, bytes(pk[f, c, hdr:hdr + max(plen, 0)]), bool(radio[c]), int(rng.integers(0, 2 ** 32))))
+            if rng.integers(0, 5) == 0:
+                pkt[0] &= 0x3F                                            # wrong version
+            if radio[c] and rng.integers(0, 5) == 0:
+                pkt[13] = 0x66                                            # wrong extension profile
+            if rng.integers(0, 4) == 0:
+                pkt[1] |= 0x80                                            # marker
+            pkt = bytes(pkt)[:stride]
+            pk[f, c, :len(pkt)] = np.frombuffer(pkt, np.uint8)
+            sizes[f, c] = size
+    return pk, sizes, radio
+
+
+@pytest.mark.parametrize("stride,n", [(180, 160), (192, 160), (276, 256), (64, 20)])
+def test_depayload_vs_oracle(ctx, orc, stride, n):
+    torch = gu.torch_cuda()
+    C_, F_ = 29, 11
+    pk, sizes, radio = _make_packets(orc, C_, F_, stride, n, seed=stride + n)
+    d_pl, d_len, d_info = gu.dev_zeros(F_ * C_ * n, 0xEE), gu.dev_zeros(F_ * C_ * 2, 0xEE), gu.dev_zeros(F_ * C_ * 8, 0xEE)
+    ctx.depayload(gu.to_dev(pk), gu.to_dev(sizes), gu.to_dev(radio), C_, F_, stride, n, d_pl, d_len, d_info)
+    torch.cuda.synchronize()
+    epl, elen, einfo = orc.depayload(pk, sizes, radio, n)
+    assert np.array_equal(gu.to_host(d_len, "<u2", (F_, C_)), elen)
+    ginfo = gu.to_host(d_info, capi.RTP_INFO, (F_, C_))
+    for f in capi.RTP_INFO.names:
+        assert np.array_equal(ginfo[f], einfo[f]), f
+    assert np.array_equal(gu.to_host(d_pl, np.uint8, (F_, C_, n)), epl)
+    # every class of packet occurred
+    fl = einfo["flags"]
+    for bit in (capi.RTP_KEEPALIVE, capi.RTP_METERED, capi.RTP_RUNT, capi.RTP_OVERSIZE, capi.RTP_ED137_OK):
+        assert (fl & bit).any(), bit
+    # ED-137 word fields with the reference's masks (Functions.cpp:1018,1045,1136,1148)
+    v = einfo["ed137"].astype(np.uint64)
+    assert np.array_equal((v & 0xe0000000) >> 29, (ginfo["ed137"].astype(np.uint64) >> 29) & 7)
+
+
+def test_depayload_then_meter_equals_direct(ctx, orc):
+    """packets -> igdsp_depayload -> igdsp_decode_meter(len) == oracle meter on the oracle's payloads;
+    full 180-byte slots without a size array take the same route."""
+    torch = gu.torch_cuda()
+    C_, F_, stride, n = 64, 6, 180, 160
+    pk, sizes, radio = _make_packets(orc, C_, F_, stride, n, seed=77)
+    codec = np.where(np.arange(C_) & 1, 8, 0).astype(np.uint8)
+    d_pl, d_len, d_info = gu.dev_zeros(F_ * C_ * n), gu.dev_zeros(F_ * C_ * 2), gu.dev_zeros(F_ * C_ * 8)
+    d_st = gu.dev_zeros(F_ * C_ * 16, 0xEE)
+    d_cd = gu.to_dev(codec)
+    ctx.depayload(gu.to_dev(pk), gu.to_dev(sizes), gu.to_dev(radio), C_, F_, stride, n, d_pl, d_len, d_info)
+    ctx.decode_meter(d_pl, d_cd, C_, F_, n, d_st, length=d_len)
+    torch.cuda.synchronize()
+    epl, elen, _ = orc.depayload(pk, sizes, radio, n)
+    est = orc.decode_meter(epl, codec, length=elen)
+    gu.assert_stats_equal(gu.to_host(d_st, capi.FRAME_STATS, (F_, C_)), est, n=elen)
+    # sizes == NULL: every slot is a full radio packet (the steady state) -> dense payload for the fast path
+    radio1 = np.ones((C_,), np.uint8)
+    body = orc.gen_uniform(F_ * C_ * n, seed=3).reshape(F_, C_, n)
+    pk2 = np.zeros((F_, C_, stride), np.uint8)
+    for f in range(F_):
+        for c in range(C_):
+            pk2[f, c] = np.frombuffer(hu.rtp_packet(int(codec[c]), f, body[f, c].tobytes(), True, 0x20000000), np.uint8)
+    ctx.depayload(gu.to_dev(pk2), None, gu.to_dev(radio1), C_, F_, stride, n, d_pl, d_len, d_info)
+    ctx.decode_meter(d_pl, d_cd, C_, F_, n, d_st)
+    torch.cuda.synchronize()
+    assert np.array_equal(gu.to_host(d_pl, np.uint8, (F_, C_, n)), body)
+    assert np.all(gu.to_host(d_len, "<u2") == n)
+    gu.assert_stats_equal(gu.to_host(d_st, capi.FRAME_STATS, (F_, C_)), orc.decode_meter(body, codec), n=n)
+
+
+def test_depayload_agrees_with_host_transport_rtp_cb(ctx, orc):
+    """The C++ host mirror's transport_rtp_cb (an independent implementation of TransportAdapter.cpp:240-292)
+    sees the same payload bytes / lengths / ED-137 words as the device kernel."""
+    torch = gu.torch_cuda()
+    L = hu.load()
+    C_, F_, stride, n = 6, 9, 276, 256
+    pk, sizes, radio = _make_packets(orc, C_, F_, stride, n, seed=5)
+    d_pl, d_len, d_info = gu.dev_zeros(F_ * C_ * n), gu.dev_zeros(F_ * C_ * 2), gu.dev_zeros(F_ * C_ * 8)
+    ctx.depayload(gu.to_dev(pk), gu.to_dev(sizes), gu.to_dev(radio), C_, F_, stride, n, d_pl, d_len, d_info)
+    torch.cuda.synchronize()
+    gpl, ginfo = gu.to_host(d_pl, np.uint8, (F_, C_, n)), gu.to_host(d_info, capi.RTP_INFO, (F_, C_))
+    adapters = [L.igdsp_host_adapter_new(100 + c, int(radio[c])) for c in range(C_)]
+    checked = 0
+    for f in range(F_):
+        for c in range(C_):
+            size = int(sizes[f, c])
+            hdr = 20 if radio[c] else 12
+            if size < hdr:
+                continue                                                    # the mirror ignores runts
+            a = adapters[c].contents
+            before = a.payload_bufSize
+            L.transport_rtp_cb(adapters[c], pk[f, c].tobytes(), size)
+            if size - hdr > 256:
+                assert a.payload_bufSize == before
+                continue
+            assert a.payload_bufSize == int(ginfo[f, c]["payload_len"]) == size - hdr
+            if ginfo[f, c]["flags"] & capi.RTP_METERED:
+                assert bytes(a.payload_buff[: size - hdr]) == gpl[f, c, : size - hdr].tobytes()
+                checked += 1
+            if radio[c] and int(ginfo[f, c]["pt"]) in (0, 8, 18, 123):
+                import socket
+                assert socket.ntohl(a.ed137_value) == int(ginfo[f, c]["ed137"])
+    assert checked > 10
+    for a in adapters:
+        L.igdsp_host_adapter_free(a)
