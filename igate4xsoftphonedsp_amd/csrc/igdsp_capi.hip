@@ -348,10 +348,10 @@ int igdsp_roundtrip_peakhold(igdsp_ctx *ctx, const uint8_t *d_payload, const uin
     if (int rc = check_shape(C, F, n)) return rc;
     // the fused channel-major kernel covers the tuned geometry; anything else is rejected
     // rather than silently routed elsewhere (callers compose decode_meter + encode + hold_update).
-    const bool fused_ok = (n == (uint32_t)kFrame) && (C % kChunkFrames == 0) &&
+    const bool fused_ok = (n == (uint32_t)kFrame) && (C % 64u == 0) &&
                           ((reinterpret_cast<uintptr_t>(d_payload) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) &&
                           ((reinterpret_cast<uintptr_t>(d_stats) & 15u) == 0);
-    if (!fused_ok) return fail(ctx, IGDSP_EINVAL, "roundtrip_peakhold needs n == 160, C % 32 == 0 and 16-byte aligned buffers");
+    if (!fused_ok) return fail(ctx, IGDSP_EINVAL, "roundtrip_peakhold needs n == 160, C % 64 == 0 and 16-byte aligned buffers");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_roundtrip(cfg_of(ctx), d_payload, d_codec, C, F, n, d_out, d_stats, d_hold, d_gate, variant, pick(ctx, stream)));
     return IGDSP_OK;

@@ -401,9 +401,25 @@ __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half
         if (k == 1) {                           // piece j complete
             strip_half[j * 64 + lane] = make_uint2(sum, peak | (bsum << 16) | probe_fail(d[j], pm[j]));
             if (STORE_PCM) {
-                uint4 *op = pcm_half + 2u * ((uint32_t)j * 64u + lane);
-                st_stream(op, make_uint4(o[0], o[1], o[2], o[3]));
-                st_stream(op + 1, make_uint4(o[4], o[5], o[6], o[7]));
+                // Each lane holds 32 contiguous PCM bytes (A = o[0..3], B = o[4..7]); four neighbouring lanes hold
+                // 128.  A quad-local DPP shuffle regroups them so that one store instruction writes 64 contiguous
+                // bytes per quad (lane i of the quad stores 16-byte chunk i, the second store chunk 4 + i)
+                // instead of 16-byte pieces at 32-byte stride.  Plain (cached) stores: L2 merges the two halves
+                // of a line; the nontemporal form measured 18 % slower on this pattern.
+                const bool odd = (lane & 1u) != 0u;
+                uint32_t s1[4], s2[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t ta = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o[i], 0x50, 0xF, 0xF, false);       // quad_perm [0,0,1,1]
+                    const uint32_t tb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o[4 + i], 0x50, 0xF, 0xF, false);
+                    const uint32_t ua = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o[i], 0xFA, 0xF, 0xF, false);       // quad_perm [2,2,3,3]
+                    const uint32_t ub = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o[4 + i], 0xFA, 0xF, 0xF, false);
+                    s1[i] = odd ? tb : ta;
+                    s2[i] = odd ? ub : ua;
+                }
+                uint4 *op = pcm_half + ((uint32_t)j * 128u + (lane >> 2) * 8u + (lane & 3u));
+                op[0] = make_uint4(s1[0], s1[1], s1[2], s1[3]);
+                op[4] = make_uint4(s2[0], s2[1], s2[2], s2[3]);
             }
             d[j] = ld_stream(refill + j * 64);
             sum = 0; peak = 0; bsum = 0;
@@ -430,22 +446,25 @@ __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half
 // ============================================================================
 constexpr int kSuperFrames = 2 * kChunkFrames;                 // 64
 constexpr int kStripEntries = kSuperFrames * kPiecesPerFrame;  // 640 x 8 B = 5 KiB per wave
-constexpr int kChunkLdsEntries = kLutEntries + kWavesPerBlock * kStripEntries;   // 64 KiB + 80 KiB
+// waves per block: 16 (1024 threads, 128 VGPRs) for the meter-only kernel; the PCM-store variants carry
+// eight more live registers per lane and run 12 waves (768 threads, up to 168 VGPRs) instead of spilling.
+template <bool STORE_PCM> struct ChunkGeom { static constexpr int kWaves = STORE_PCM ? 12 : kWavesPerBlock; };
 
 // DIAG: a separate diagnostic instantiation (never the shipped path) that stamps where a
 // wave's cycles go; the stamps leave only through `diag`, no output is computed from them.
 template <bool STORE_PCM, bool AGG, bool DIAG = false>
-__global__ __launch_bounds__(kBlockThreads) void k_meter_chunk64(
+__global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chunk64(
     const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t n_frames,
     igdsp_frame_stats *__restrict__ stats, int16_t *__restrict__ pcm, igdsp_aggregate *agg, uint32_t rank,
     uint64_t *__restrict__ diag = nullptr)
 {
-    __shared__ uint2 lds[kChunkLdsEntries];
+    constexpr int kWaves = ChunkGeom<STORE_PCM>::kWaves;
+    __shared__ uint2 lds[kLutEntries + kWaves * kStripEntries];   // 64 KiB LUT + 5 KiB strip per wave
     __shared__ uint32_t next_item;
     uint64_t d_t0 = 0, d_t1 = 0, d_iter = 0, d_rt0 = 0, d_setup = 0, d_px = 0, d_py = 0, d_red = 0;
     if (DIAG) { d_t0 = now_cycles(); d_rt0 = __builtin_amdgcn_s_memrealtime(); }
     fill_lut(lds);
-    if (threadIdx.x == 0) next_item = kWavesPerBlock;            // items 0..15 are the waves' first picks
+    if (threadIdx.x == 0) next_item = kWaves;                    // items 0..kWaves-1 are the waves' first picks
     __syncthreads();
     if (DIAG) d_t1 = now_cycles();
 
@@ -546,58 +565,65 @@ __global__ __launch_bounds__(kBlockThreads) void k_meter_chunk64(
         }
     }
     if (DIAG && lane == 0 && diag != nullptr) {
-        uint64_t *o = diag + (uint64_t)(blockIdx.x * kWavesPerBlock + wave) * 12u;
+        uint64_t *o = diag + (uint64_t)(blockIdx.x * kWaves + wave) * 12u;
         o[0] = d_t0; o[1] = d_t1; o[2] = now_cycles(); o[3] = d_setup; o[4] = d_px; o[5] = d_iter; o[6] = d_py;
         o[7] = __builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID, bits [3:0]
         o[8] = d_rt0; o[9] = __builtin_amdgcn_s_memrealtime(); o[10] = d_red; o[11] = wave;
     }
     if (AGG && agg != nullptr)   // kernel-argument uniform: every thread of the block takes the same side
-        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kWavesPerBlock, a_sumsq, (uint64_t)a_frames * kFrame, a_frames,
+        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kWaves, a_sumsq, (uint64_t)a_frames * kFrame, a_frames,
                          a_sil, a_clip, a_bm, a_peak);
 }
 
 // ============================================================================
-// a2 — G.711 compression, branch-free, segment by count-leading-zeros.
+// a2 — G.711 compression.  ONE branch-free formulation serves both laws and both encoder lineages
+// (include/igdsp.h): per-law constants select bias / rounding, the segment comes from count-leading-
+// zeros.  With msb = 31 - clz(mag):
+//   SUN16  mu : mag = min(|v| + 0x84, 0x7FFF)                 A : mag = v >= 0 ? v : max(-v - 8, 0)
+//          seg = max(msb,7) - 7        step = (mag >> (max(msb, mu?7:8) - 4)) & 15
+//   G191   mu : mag = min(|v>>2| + 0x21, 0x1FFF)              A : mag = (v>>3) ^ sign   (= -x-1 for x < 0)
+//          seg = max(msb, mu?5:4) - (mu?5:4)   step = (mag >> (max(msb,5) - 4)) & 15
+//   code = (seg<<4 | step) ^ (mu ? 0xFF : 0xD5) ^ (v < 0 ? 0x80 : 0)
+// (clamping mag is identical to the classic "segment 8 -> 0x7F ^ mask" overflow rule).
 // ============================================================================
+struct EncK { int k_and, k_add, sh; uint32_t c_shift, c_seg, base; };
+
 template <int VARIANT>
-__device__ __forceinline__ uint32_t lin2ulaw(int v)
+__device__ __forceinline__ EncK enc_consts(bool alaw)
 {
-    uint32_t mag, flip = (v < 0) ? 0x7Fu : 0xFFu;
+    EncK k;
     if (VARIANT == IGDSP_ENC_SUN16) {
-        mag = (uint32_t)(v < 0 ? -v : v) + 0x84u;                 // 0x84 .. 32900
-        if (mag > 0x7FFFu) return 0x7Fu ^ flip;
-        const uint32_t s = 24u - (uint32_t)__clz((int)mag);       // bit7 -> seg 0
-        return ((s << 4) | ((mag >> (s + 3u)) & 15u)) ^ flip;
+        k.k_and = alaw ? -8 : 0; k.k_add = alaw ? 0 : 0x84; k.sh = 0;
+        k.c_shift = alaw ? 23u : 24u;      // 31 - floor(msb) for the step shift
+        k.c_seg = 24u;                     // 31 - 7
     } else {
-        const int v14 = v >> 2;
-        mag = min((uint32_t)(v14 < 0 ? -v14 : v14), 8159u) + 0x21u;   // 0x21 .. 8192
-        const uint32_t s = 26u - (uint32_t)__clz((int)mag);       // bit5 -> seg 0
-        if (s >= 8u) return 0x7Fu ^ flip;
-        return ((s << 4) | ((mag >> (s + 1u)) & 15u)) ^ flip;
+        k.k_and = alaw ? 0 : 1; k.k_add = alaw ? 0 : 0x21; k.sh = alaw ? 3 : 2;
+        k.c_shift = 26u;                   // 31 - 5
+        k.c_seg = alaw ? 27u : 26u;        // 31 - {4,5}
     }
+    k.base = alaw ? 0xD5u : 0xFFu;
+    return k;
 }
 
 template <int VARIANT>
-__device__ __forceinline__ uint32_t lin2alaw(int v)
+__device__ __forceinline__ uint32_t enc_uni(int v, const EncK k)
 {
-    uint32_t mag, flip = (v >= 0) ? 0xD5u : 0x55u;
+    int mag;
+    const int sign = v >> 31;                                   // -1 for negative samples
     if (VARIANT == IGDSP_ENC_SUN16) {
-        const int m = (v >= 0) ? v : max(-v - 8, 0);
-        mag = (uint32_t)m;                                        // <= 32767
-        const uint32_t s = (mag <= 0xFFu) ? 0u : 24u - (uint32_t)__clz((int)mag);
-        const uint32_t q = (s < 2u) ? (mag >> 4) : (mag >> (s + 3u));
-        return ((s << 4) | (q & 15u)) ^ flip;
+        const int av = (v ^ sign) - sign;                       // |v|, 32768 for -32768
+        mag = min(max(av + ((sign & k.k_and) + k.k_add), 0), 0x7FFF);
     } else {
-        const int v13 = v >> 3;
-        mag = (uint32_t)(v13 ^ (v13 >> 31));                      // v13 >= 0 ? v13 : -v13 - 1   (<= 4095)
-        const uint32_t s = (mag <= 0x1Fu) ? 0u : 27u - (uint32_t)__clz((int)mag);
-        const uint32_t q = (s < 2u) ? (mag >> 1) : (mag >> s);
-        return ((s << 4) | (q & 15u)) ^ flip;
+        const int vd = v >> k.sh;                               // arithmetic: floors negatives
+        const int t = vd ^ sign;                                // x >= 0 ? x : -x - 1
+        mag = min(t + (sign & k.k_and) + k.k_add, 0x1FFF);      // mu: |x| + 0x21 ; A: -x - 1
     }
+    const uint32_t c = (uint32_t)__clz(mag);                    // 32 for mag == 0
+    const uint32_t shift = 27u - min(c, k.c_shift);             // max(msb, floor) - 4
+    const uint32_t sg = k.c_seg - min(c, k.c_seg);              // max(msb, f) - f
+    const uint32_t step = ((uint32_t)mag >> shift) & 15u;
+    return ((sg << 4) | step) ^ k.base ^ ((uint32_t)sign & 0x80u);
 }
-
-template <int VARIANT>
-__device__ __forceinline__ uint32_t enc1(int v, bool alaw) { return alaw ? lin2alaw<VARIANT>(v) : lin2ulaw<VARIANT>(v); }
 
 // 8 samples (16 B) per lane in, 8 codes (8 B) out; requires n % 8 == 0 and 16 B aligned pcm.
 template <int VARIANT>
@@ -608,13 +634,13 @@ __global__ __launch_bounds__(256) void k_encode_v8(const int16_t *__restrict__ p
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (uint64_t)gridDim.x * blockDim.x) {
         const uint4 d = ld_stream(reinterpret_cast<const uint4 *>(pcm) + g);
         const uint32_t c = (uint32_t)((g / groups_per_frame) % C);
-        const bool alaw = codec[c] == IGDSP_PT_PCMA;
+        const EncK k = enc_consts<VARIANT>(codec[c] == IGDSP_PT_PCMA);
         const uint32_t w[4] = {d.x, d.y, d.z, d.w};
         uint32_t r[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            r[2 * i] = enc1<VARIANT>((int)(int16_t)(w[i] & 0xFFFFu), alaw);
-            r[2 * i + 1] = enc1<VARIANT>((int)(int16_t)(w[i] >> 16), alaw);
+            r[2 * i] = enc_uni<VARIANT>((int)(int16_t)(w[i] & 0xFFFFu), k);
+            r[2 * i + 1] = enc_uni<VARIANT>((int)(int16_t)(w[i] >> 16), k);
         }
         uint2 o;
         o.x = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
@@ -629,30 +655,86 @@ __global__ __launch_bounds__(256) void k_encode_scalar(const int16_t *__restrict
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t c = (uint32_t)((i / n) % C);
-        out[i] = (uint8_t)enc1<VARIANT>((int)pcm[i], codec[c] == IGDSP_PT_PCMA);
+        out[i] = (uint8_t)enc_uni<VARIANT>((int)pcm[i], enc_consts<VARIANT>(codec[c] == IGDSP_PT_PCMA));
     }
 }
 
 // ============================================================================
-// Config #5 — fused decode -> stats -> re-encode -> per-channel hold.
-// Channel-chunk-major: one wavefront owns 32 consecutive CHANNELS and walks all
-// F frames of them (frame f of those channels is a contiguous 5120 B strip at
-// stride C*160), so the hold state lives in the frame lanes' registers for the
-// whole launch and is written once.  Needs C % 32 == 0 and n == 160; other
-// shapes go through decode_meter + encode + hold_update.
+// Config #5 — fused decode -> stats -> re-encode -> per-channel hold (a1 + a2 + a5 + a6).
+// Channel-group-major: one wavefront owns 64 consecutive CHANNELS and walks all F frames of them
+// (frame f of those channels is one contiguous 10 240-byte super-chunk at stride C*160), so the hold
+// state — keeplogAudioLevel's count / sum / max / min (Functions.cpp:2126-2145) plus peak-hold and
+// sum of squares — lives in the frame lanes' registers for the whole launch and is written once.
+// Same LUT, strip and load pipeline as k_meter_chunk64; the re-encode is the full compression
+// arithmetic (enc_uni) applied to the decoded PCM value, not a shortcut.  Needs C % 64 == 0, n == 160.
 // ============================================================================
+#ifndef IGDSP_RT_WAVES
+#define IGDSP_RT_WAVES 8
+#endif
+constexpr int kRtWaves = IGDSP_RT_WAVES;   // 512 threads: the encoder's temporaries need well over 128 VGPRs
+
 template <int VARIANT>
-__global__ __launch_bounds__(kBlockThreads) void k_roundtrip_chunk32(
+__device__ __forceinline__ void roundtrip_half(const uint2 *lut, uint2 *strip_half, uint4 (&d)[kLoadsPerChunk],
+                                               const uint32_t (&lm)[kLoadsPerChunk], const uint32_t (&pm)[kLoadsPerChunk],
+                                               const uint32_t off, const uint32_t lane, uint4 *out_half, const uint4 *refill,
+                                               const bool do_refill)
+{
+    uint2 e[2][8];
+    uint32_t wa[2], wb[2];
+    auto issue = [&](int u) {
+        const int j = u >> 1, k = u & 1;
+        wa[k] = (u & 1) ? d[j].z : d[j].x;
+        wb[k] = (u & 1) ? d[j].w : d[j].y;
+        const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lm[j], tb = (wb[k] & 0x7F7F7F7Fu) | lm[j];
+        e[k][0] = lut_at(lut, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lut, ta, off, 0x0C0C0500u);
+        e[k][2] = lut_at(lut, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lut, ta, off, 0x0C0C0700u);
+        e[k][4] = lut_at(lut, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lut, tb, off, 0x0C0C0500u);
+        e[k][6] = lut_at(lut, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lut, tb, off, 0x0C0C0700u);
+    };
+    auto recode4 = [&](uint32_t w, const uint2 &e0, const uint2 &e1, const uint2 &e2, const uint2 &e3, const EncK k) {
+        // decoded PCM value of each code (sign bit set = positive), then the compressor on that value
+        const int x0 = (w & 0x80u) ? (int)e0.y : -(int)e0.y, x1 = (w & 0x8000u) ? (int)e1.y : -(int)e1.y;
+        const int x2 = (w & 0x800000u) ? (int)e2.y : -(int)e2.y, x3 = (w & 0x80000000u) ? (int)e3.y : -(int)e3.y;
+        return enc_uni<VARIANT>(x0, k) | (enc_uni<VARIANT>(x1, k) << 8) | (enc_uni<VARIANT>(x2, k) << 16) | (enc_uni<VARIANT>(x3, k) << 24);
+    };
+    uint32_t sum = 0, peak = 0, bsum = 0;
+    uint32_t o[4];
+    issue(0);
+#pragma unroll
+    for (int u = 0; u < 2 * kLoadsPerChunk; ++u) {
+        const int j = u >> 1, k = u & 1;
+        if (u + 1 < 2 * kLoadsPerChunk) issue(u + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const EncK ek = enc_consts<VARIANT>(lm[j] != 0u);
+        bsum = __builtin_amdgcn_sad_u8(wa[k], 0u, bsum);
+        bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
+        sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
+        sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
+        peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
+        peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
+        o[2 * k] = recode4(wa[k], e[k][0], e[k][1], e[k][2], e[k][3], ek);
+        o[2 * k + 1] = recode4(wb[k], e[k][4], e[k][5], e[k][6], e[k][7], ek);
+        if (k == 1) {
+            strip_half[j * 64 + lane] = make_uint2(sum, peak | (bsum << 16) | probe_fail(d[j], pm[j]));
+            st_stream(out_half + j * 64, make_uint4(o[0], o[1], o[2], o[3]));
+            if (do_refill) d[j] = ld_stream(refill + j * 64);
+            sum = 0; peak = 0; bsum = 0;
+        }
+    }
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(kRtWaves * 64) void k_roundtrip_chunk64(
     const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F,
     uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats, igdsp_chan_hold *__restrict__ hold,
     const uint8_t *__restrict__ gate)
 {
-    __shared__ uint2 lds[kLutEntries + kWavesPerBlock * kPiecesPerChunk];
+    __shared__ uint2 lds[kLutEntries + kRtWaves * kStripEntries];
     fill_lut(lds);
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2 *strip = lds + kLutEntries + wave * kPiecesPerChunk;
+    uint2 *strip = lds + kLutEntries + wave * kStripEntries;
     const uint32_t off = (lane & 31u) * 8u;
     uint32_t fr[kLoadsPerChunk], pm[kLoadsPerChunk];
 #pragma unroll
@@ -661,69 +743,55 @@ __global__ __launch_bounds__(kBlockThreads) void k_roundtrip_chunk32(
         fr[j] = p / 10u;
         pm[j] = probe_mask(p - fr[j] * 10u);
     }
-    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
-    const uint32_t wave_id = wave * gridDim.x + blockIdx.x;
-    const uint32_t n_cchunks = C / kChunkFrames;
-    const uint64_t fstride16 = (uint64_t)C * kFrame / 16u;   // uint4 units between frames
+    const uint32_t total_waves = gridDim.x * kRtWaves;
+    const uint32_t n_groups = C / kSuperFrames;
+    const uint32_t fstride16 = C * (uint32_t)kPiecesPerFrame;       // uint4 units between frames of one channel group
 
-    for (uint32_t cc = wave_id; cc < n_cchunks; cc += total_waves) {
-        const uint32_t c0 = cc * kChunkFrames;
-        const uint32_t cme = c0 + (lane & 31u);
-        const uint32_t my_alaw = (codec[cme] == IGDSP_PT_PCMA) ? 1u : 0u;
+    for (uint32_t cg = wave * gridDim.x + blockIdx.x; cg < n_groups; cg += total_waves) {
+        const uint32_t c0 = cg * kSuperFrames, cme = c0 + lane;
+        const bool my_alaw = codec[cme] == IGDSP_PT_PCMA;
         const bool open = (gate == nullptr) || (gate[cme] != 0);
-        igdsp_chan_hold h;
-        if (lane < (uint32_t)kChunkFrames) h = hold[cme];
-        uint32_t alaw_j[kLoadsPerChunk];
+        igdsp_chan_hold h = hold[cme];
+        const uint64_t amask = __ballot(my_alaw);
+        const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
+        uint32_t lm0[kLoadsPerChunk], lm1[kLoadsPerChunk];
 #pragma unroll
-        for (int j = 0; j < kLoadsPerChunk; ++j) alaw_j[j] = (uint32_t)__shfl((int)my_alaw, (int)fr[j], 64);
+        for (int j = 0; j < kLoadsPerChunk; ++j) {
+            lm0[j] = (uint32_t)__builtin_amdgcn_sbfe(am_lo, fr[j], 1) & 0x80808080u;
+            lm1[j] = (uint32_t)__builtin_amdgcn_sbfe(am_hi, fr[j], 1) & 0x80808080u;
+        }
+        const uint4 *src = reinterpret_cast<const uint4 *>(payload) + ((uint64_t)c0 * kPiecesPerFrame + lane);
+        uint4 *dst = reinterpret_cast<uint4 *>(out) + ((uint64_t)c0 * kPiecesPerFrame + lane);
 
-        const uint4 *src = reinterpret_cast<const uint4 *>(payload + (uint64_t)c0 * kFrame) + lane;
-        uint4 *dst = reinterpret_cast<uint4 *>(out + (uint64_t)c0 * kFrame) + lane;
+        uint4 X[kLoadsPerChunk], Y[kLoadsPerChunk];
+#pragma unroll
+        for (int j = 0; j < kLoadsPerChunk; ++j) X[j] = ld_stream(src + j * 64);
+#pragma unroll
+        for (int j = 0; j < kLoadsPerChunk; ++j) Y[j] = ld_stream(src + kPiecesPerChunk + j * 64);
 
-        auto fetch = [&](uint4 (&d)[kLoadsPerChunk], uint32_t f) {
-#pragma unroll
-            for (int j = 0; j < kLoadsPerChunk; ++j) d[j] = ld_stream(src + (uint64_t)f * fstride16 + j * 64);
-        };
-        auto process = [&](const uint4 (&cur)[kLoadsPerChunk], uint32_t f) {
-#pragma unroll
-            for (int j = 0; j < kLoadsPerChunk; ++j) {
-                const bool alaw = alaw_j[j] != 0u;
-                uint32_t sum = 0, peak = 0, bsum = 0;
-                uint4 o0, o1;   // decoded PCM, 16 samples
-                piece16<true>(lds, cur[j], alaw ? 0x80808080u : 0u, off, sum, peak, bsum, o0, o1);
-                strip[j * 64 + lane] = make_uint2(sum, peak | (bsum << 16) | probe_fail(cur[j], pm[j]));
-                // re-encode the decoded PCM (full compression arithmetic, not a shortcut)
-                const uint32_t pw[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
-                uint32_t cw[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t r0 = enc1<VARIANT>((int)(int16_t)(pw[2 * i] & 0xFFFFu), alaw);
-                    const uint32_t r1 = enc1<VARIANT>((int)(int16_t)(pw[2 * i] >> 16), alaw);
-                    const uint32_t r2 = enc1<VARIANT>((int)(int16_t)(pw[2 * i + 1] & 0xFFFFu), alaw);
-                    const uint32_t r3 = enc1<VARIANT>((int)(int16_t)(pw[2 * i + 1] >> 16), alaw);
-                    cw[i] = r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
-                }
-                dst[(uint64_t)f * fstride16 + j * 64] = make_uint4(cw[0], cw[1], cw[2], cw[3]);
-            }
+        for (uint32_t f = 0; f < F; ++f) {
+            const bool more = f + 1u < F;                       // wave-uniform; the last frame simply skips its refill
+            const uint4 *nsrc = src + (uint64_t)(more ? f + 1u : f) * fstride16;
+            uint4 *o16 = dst + (uint64_t)f * fstride16;
+            roundtrip_half<VARIANT>(lds, strip, X, lm0, pm, off, lane, o16, nsrc, true);
+            roundtrip_half<VARIANT>(lds, strip + kPiecesPerChunk, Y, lm1, pm, off, lane, o16 + kPiecesPerChunk, nsrc + kPiecesPerChunk, true);
             wave_lds_fence();
-            if (lane < (uint32_t)kChunkFrames) {
+            {
                 const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kPiecesPerFrame);
                 uint64_t s = 0;
                 uint32_t peak = 0, bsum = 0, fail = 0;
 #pragma unroll
                 for (int i = 0; i < kPiecesPerFrame / 2; ++i) {
                     const uint4 v = row[i];
-                    s += (uint64_t)v.x + (uint64_t)v.z;
+                    s += (uint64_t)(v.x + v.z);
                     peak = max(max(peak, v.y & 0x7FFFu), v.w & 0x7FFFu);
                     bsum += ((v.y >> 16) & 0x7FFFu) + ((v.w >> 16) & 0x7FFFu);
                     fail |= v.y | v.w;
                 }
-                const uint64_t sumsq = s << 4;
                 uint32_t bm, fl;
-                *reinterpret_cast<uint4 *>(stats + (uint64_t)f * C + cme) =
-                    pack_stats(sumsq, peak, bsum, (uint32_t)kFrame, my_alaw != 0u, (fail >> 31) == 0u, bm, fl);
+                st_stream(reinterpret_cast<uint4 *>(stats + ((uint64_t)f * C + cme)), pack_stats160(s, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl));
                 if (open) {
-                    h.sumsq_acc += sumsq; h.count += 1u; h.level_sum += bm; h.samples += (uint32_t)kFrame;
+                    h.sumsq_acc += s << 4; h.count += 1u; h.level_sum += bm; h.samples += (uint32_t)kFrame;
                     h.peak_hold = (uint16_t)max((uint32_t)h.peak_hold, peak);
                     h.level_max = (uint8_t)max((uint32_t)h.level_max, bm);
                     h.level_min = (uint8_t)min((uint32_t)h.level_min, bm);
@@ -732,20 +800,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_roundtrip_chunk32(
                 }
             }
             wave_lds_fence();
-        };
-
-        uint4 cur[kLoadsPerChunk];
-        fetch(cur, 0);
-        uint32_t f = 0;
-        for (; f + 1u < F; ++f) {          // steady state: next frame's loads in flight, unconditional
-            uint4 nxt[kLoadsPerChunk];
-            fetch(nxt, f + 1u);
-            process(cur, f);
-#pragma unroll
-            for (int j = 0; j < kLoadsPerChunk; ++j) cur[j] = nxt[j];
         }
-        process(cur, f);
-        if (lane < (uint32_t)kChunkFrames) hold[cme] = h;
+        hold[cme] = h;
     }
 }
 
@@ -956,12 +1012,14 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
     if (variant != 1 && chunk_ok && n_frames >= (uint32_t)kSuperFrames) {
         const uint32_t n_super = n_frames / kSuperFrames;
         done = n_super * kSuperFrames;
-        const uint32_t grid = blocks_for(n_super, kWavesPerBlock, (uint32_t)cfg.compute_units);
         uint64_t *nodiag = nullptr;
         if (pcm) {
-            if (agg) hipLaunchKernelGGL((k_meter_chunk64<true, true>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag);
-            else     hipLaunchKernelGGL((k_meter_chunk64<true, false>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag);
+            constexpr int w = ChunkGeom<true>::kWaves;
+            const uint32_t grid = blocks_for(n_super, w, (uint32_t)cfg.compute_units);
+            if (agg) hipLaunchKernelGGL((k_meter_chunk64<true, true>), dim3(grid), dim3(w * 64), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag);
+            else     hipLaunchKernelGGL((k_meter_chunk64<true, false>), dim3(grid), dim3(w * 64), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag);
         } else {
+            const uint32_t grid = blocks_for(n_super, kWavesPerBlock, (uint32_t)cfg.compute_units);
             if (agg) hipLaunchKernelGGL((k_meter_chunk64<false, true>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag);
             else     hipLaunchKernelGGL((k_meter_chunk64<false, false>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag);
         }
@@ -1012,9 +1070,9 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, const uint8_t *payload, const 
                             const uint8_t *gate, int variant, hipStream_t s)
 {
     if ((uint64_t)C * F == 0) return hipSuccess;
-    const uint32_t grid = blocks_for(C / kChunkFrames, kWavesPerBlock, (uint32_t)cfg.compute_units);
-    if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_chunk32<IGDSP_ENC_G191>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, F, out, stats, hold, gate);
-    else                           hipLaunchKernelGGL((k_roundtrip_chunk32<IGDSP_ENC_SUN16>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, F, out, stats, hold, gate);
+    const uint32_t grid = blocks_for(C / kSuperFrames, kRtWaves, (uint32_t)cfg.compute_units);
+    if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_G191>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate);
+    else                           hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_SUN16>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate);
     (void)n;
     return hipGetLastError();
 }
