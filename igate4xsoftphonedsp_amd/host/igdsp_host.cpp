@@ -4,6 +4,7 @@
 
 #include <arpa/inet.h>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -17,8 +18,10 @@ static long long now_ms()
 }
 
 // ---------------------------------------------------------------------------------------------
-RoIP_ED137::RoIP_ED137() : inviteMode(SERVER), referenceTxQuirk(false), ed137Events(0), onValueChanged(nullptr), ctx_(nullptr)
+RoIP_ED137::RoIP_ED137() : inviteMode(SERVER), referenceTxQuirk(false), ed137Events(0), onValueChanged(nullptr), m_softPhoneID(1), ctx_(nullptr)
 {
+    std::memset(window, 0, sizeof window);
+    for (int i = 0; i < 4; ++i) window[i].OutgoingRTPmin = 255;          // roip_ed137.h:745
     for (int i = 0; i < 4; ++i) {
         radio[i] = new trx();
         std::memset(radio[i], 0, sizeof(trx));
@@ -111,7 +114,91 @@ int RoIP_ED137::tick(uint32_t *frames_done)
 }
 
 // ---------------------------------------------------------------------------------------------
+// PTT-window logger.  keeplogAudioLevel: Functions.cpp:2126-2145.  createPTTEventDataLogger: reset on
+// "pptTest_pressed" (:2155-2167), close + 10*log10 on "pptTest_released" (:2192-2222); message text :2169-2187, :2202-2215.
+void RoIP_ED137::keeplogAudioLevel(int slot, double audioInLevel)
+{
+    if (slot < 0 || slot > 3) return;
+    ptt_window &w = window[slot];
+    if (!w.eventPttSQL_In_LoggingOn) return;
+    const uint8_t out = radio[slot]->OutgoingRTP;
+    w.level_in_count += 1;
+    w.level_in = audioInLevel;
+    w.level_in_av += audioInLevel;
+    w.OutgoingRTPSum = (uint16_t)(w.OutgoingRTPSum + out);
+    if (audioInLevel > w.level_in_max) w.level_in_max = audioInLevel;
+    if (audioInLevel < w.level_in_min) w.level_in_min = audioInLevel;
+    if (out > w.OutgoingRTPmax) w.OutgoingRTPmax = out;
+    if (out < w.OutgoingRTPmin) w.OutgoingRTPmin = out;
+}
+
+static int ptt_json(char *json, size_t cap, int id, const char *ev, double a, double b, double c, const char *url, int x, int y, int z)
+{
+    // QString::arg(double) prints like %g (6 significant digits); uint8_t arguments promote to int.
+    // The key "radioUrl " carries the reference's trailing blank.
+    int n = std::snprintf(json, cap,
+        "{\"menuID\"                       :\"PTTEventDataLogger\", \"softPhoneID\"                  :%d, "
+        "\"Ptt\"                          :\"%s\", \"level_in_av\"                  :%g, "
+        "\"level_in_max\"                 :%g, \"level_in_min\"                 :%g, "
+        "\"radioUrl \"                    :\"%s\",\"OutgoingRTPAv\"                :%d, "
+        "\"OutgoingRTPmax\"               :%d, \"OutgoingRTPmin\"               :%d }",
+        id, ev, a, b, c, url ? url : "", x, y, z);
+    return (n < 0 || (size_t)n >= cap) ? 0 : n;
+}
+
+int RoIP_ED137::createPTTEventDataLogger(int slot, const char *strEvent, const char *url, double audioInLevel, char *json, size_t cap)
+{
+    if (slot < 0 || slot > 3 || !strEvent || !json || cap == 0 || inviteMode != SERVER) return 0;
+    ptt_window &w = window[slot];
+    trx *r = radio[slot];
+    json[0] = 0;
+    if (std::strcmp(strEvent, "pptTest_pressed") == 0) {
+        if (w.eventPttSQL_In_LoggingOn) return 0;
+        w.eventPttSQL_In_LoggingOn = true;
+        w.level_in_count = 0;
+        w.level_in = 10 * std::log10(audioInLevel);
+        w.level_in_av = 0; w.level_in_max = 0; w.level_in_min = 255;
+        w.OutgoingRTPSum = 0; w.OutgoingRTPmax = 0; w.OutgoingRTPmin = 255;
+        igdsp_reset_hold(ctx_, (uint32_t)(2 * slot));            // the per-frame device window opens with it
+        igdsp_reset_hold(ctx_, (uint32_t)(2 * slot + 1));
+        return ptt_json(json, cap, m_softPhoneID, strEvent, w.level_in, w.level_in, w.level_in, url, r->OutgoingRTP, r->OutgoingRTP, r->OutgoingRTP);
+    }
+    if (std::strcmp(strEvent, "pptTest_released") == 0) {
+        if (!w.eventPttSQL_In_LoggingOn) return 0;
+        w.eventPttSQL_In_LoggingOn = false;
+        w.level_in_av = 10 * std::log10(w.level_in_av / w.level_in_count);
+        w.level_in_max = 10 * std::log10(w.level_in_max);
+        w.level_in_min = 10 * std::log10(w.level_in_min);
+        w.OutgoingRTPav = w.level_in_count ? (uint8_t)(w.OutgoingRTPSum / w.level_in_count) : 0;   // the reference divides unguarded
+        const int n = ptt_json(json, cap, m_softPhoneID, strEvent, w.level_in_av, w.level_in_max, w.level_in_min, url,
+                               w.OutgoingRTPav, w.OutgoingRTPmax, w.OutgoingRTPmin);
+        w.level_in_count = 0; w.level_in = 0; w.level_in_av = 0; w.level_in_max = 0; w.level_in_min = 255;
+        return n;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 extern "C" {
+
+int igdsp_host_keeplog(void *h, int slot, double audioInLevel)
+{
+    if (!h) return IGDSP_EINVAL;
+    static_cast<RoIP_ED137 *>(h)->keeplogAudioLevel(slot, audioInLevel);
+    return IGDSP_OK;
+}
+
+int igdsp_host_ptt_event(void *h, int slot, const char *strEvent, const char *url, double audioInLevel, char *json, size_t cap)
+{
+    return h ? static_cast<RoIP_ED137 *>(h)->createPTTEventDataLogger(slot, strEvent, url, audioInLevel, json, cap) : 0;
+}
+
+int igdsp_host_get_window(void *h, int slot, ptt_window *out)
+{
+    if (!h || !out || slot < 0 || slot > 3) return IGDSP_EINVAL;
+    *out = static_cast<RoIP_ED137 *>(h)->window[slot];
+    return IGDSP_OK;
+}
 
 int decodeRtp(void *pkt, custom_rtp_hdr **hdr)
 {
@@ -212,6 +299,7 @@ int igdsp_host_get_trx(void *h, int slot, trx *out)
     return IGDSP_OK;
 }
 
+igdsp_ctx *igdsp_host_ctx(void *h) { return h ? static_cast<RoIP_ED137 *>(h)->ctx() : nullptr; }
 uint32_t igdsp_host_ed137_events(void *h) { return h ? static_cast<RoIP_ED137 *>(h)->ed137Events : 0; }
 
 // ---------------------------------------------------------------------------------------------

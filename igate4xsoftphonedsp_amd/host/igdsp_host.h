@@ -71,6 +71,15 @@ struct trx {                                 // roip_ed137.h:741-750 (level slot
     uint8_t  in_flags, out_flags;
 };
 
+// PTT-window level logger state, field for field after trx (roip_ed137.h:719-745)
+struct ptt_window {
+    bool     eventPttSQL_In_LoggingOn;
+    int      level_in_count;
+    double   level_in, level_in_av, level_in_max, level_in_min;
+    uint16_t OutgoingRTPSum;                 // uint16_t in the reference too: wraps after >= 257 frames of 255
+    uint8_t  OutgoingRTPav, OutgoingRTPmax, OutgoingRTPmin;
+};
+
 class RoIP_ED137 {
 public:
     // Unlike the reference singleton (roip_ed137.cpp:192) the instance owns an igdsp context; device < 0
@@ -96,6 +105,15 @@ public:
     igdsp_ctx *ctx() { return ctx_; }
     int bindRadio(int slot, int call_id);    // slot 0..3; maps RX to channel 2*slot, TX to 2*slot+1
 
+    // SURVEY 8(f) rank 3 — PTT-window level logger (Functions.cpp:2126-2230), sampled per tick like the reference.
+    // audioInLevel is the linear input level (the reference receives it over the WebSocket VU broadcast,
+    // roip_ed137.cpp:7686-7716; here callers usually pass radio[slot]->in_rms).  createPTTEventDataLogger writes
+    // the reference's "PTTEventDataLogger" JSON text into `json` and returns its length (0 = no message emitted).
+    ptt_window window[4];
+    int m_softPhoneID;
+    void keeplogAudioLevel(int slot, double audioInLevel);
+    int  createPTTEventDataLogger(int slot, const char *strEvent, const char *url, double audioInLevel, char *json, size_t cap);
+
 private:
     RoIP_ED137();
     igdsp_ctx *ctx_;
@@ -117,6 +135,10 @@ int         igdsp_host_set_mode(void *h, int invite_mode, int reference_tx_quirk
 int         igdsp_host_tick(void *h, uint32_t *frames_done);
 int         igdsp_host_get_trx(void *h, int slot, trx *out);
 uint32_t    igdsp_host_ed137_events(void *h);
+igdsp_ctx  *igdsp_host_ctx(void *h);
+int         igdsp_host_keeplog(void *h, int slot, double audioInLevel);
+int         igdsp_host_ptt_event(void *h, int slot, const char *strEvent, const char *url, double audioInLevel, char *json, size_t cap);
+int         igdsp_host_get_window(void *h, int slot, ptt_window *out);
 // WavWriter-compatible recorder (WavWriter.cpp:41-156): writeRTPWav signature, same bytes on disk
 void *igdsp_wav_start(const char *path, int rate);
 int   igdsp_wav_writeRTPWav(void *w, const char *pktbuf, const char *payloadbuf, unsigned pktlen, unsigned payloadlen);

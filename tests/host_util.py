@@ -25,6 +25,13 @@ class Trx(C.Structure):
     ]
 
 
+class PttWindow(C.Structure):
+    _fields_ = [("eventPttSQL_In_LoggingOn", C.c_bool), ("level_in_count", C.c_int), ("level_in", C.c_double),
+                ("level_in_av", C.c_double), ("level_in_max", C.c_double), ("level_in_min", C.c_double),
+                ("OutgoingRTPSum", C.c_uint16), ("OutgoingRTPav", C.c_uint8), ("OutgoingRTPmax", C.c_uint8),
+                ("OutgoingRTPmin", C.c_uint8)]
+
+
 STREAM_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_long)
 _lib = None
 
@@ -44,6 +51,10 @@ def load():
         L.igdsp_host_tick.restype = C.c_int; L.igdsp_host_tick.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.igdsp_host_get_trx.restype = C.c_int; L.igdsp_host_get_trx.argtypes = [C.c_void_p, C.c_int, C.POINTER(Trx)]
         L.igdsp_host_ed137_events.restype = C.c_uint32; L.igdsp_host_ed137_events.argtypes = [C.c_void_p]
+        L.igdsp_host_keeplog.restype = C.c_int; L.igdsp_host_keeplog.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        L.igdsp_host_ptt_event.restype = C.c_int
+        L.igdsp_host_ptt_event.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_double, C.c_char_p, C.c_size_t]
+        L.igdsp_host_get_window.restype = C.c_int; L.igdsp_host_get_window.argtypes = [C.c_void_p, C.c_int, C.POINTER(PttWindow)]
         L.transport_rtp_cb.restype = None; L.transport_rtp_cb.argtypes = [C.POINTER(TpAdapter), C.c_void_p, C.c_long]
         L.transport_send_rtp.restype = C.c_int; L.transport_send_rtp.argtypes = [C.POINTER(TpAdapter), C.c_void_p, C.c_size_t]
         L.igdsp_wav_start.restype = C.c_void_p; L.igdsp_wav_start.argtypes = [C.c_char_p, C.c_int]
