@@ -31,7 +31,8 @@ if ROOT not in sys.path:
 N_SAMPLES = 160
 # algorithmic bytes per sample, meter-only = (160 payload + 1 codec id + 16 result) / 160
 BYTES_PER_SAMPLE = {"meter": (160 + 1 + 16) / 160.0, "store": (160 + 1 + 16 + 320) / 160.0,
-                    "roundtrip": (160 + 1 + 16 + 160) / 160.0}   # config #5: read 1 + write 1 + record
+                    "roundtrip": (160 + 1 + 16 + 160) / 160.0,   # config #5: read 1 + write 1 + record
+                    "depayload": (180 + 160 + 2 + 8) / 160.0}    # 8(f) rank 1: 180 B packet in, dense payload + len + info out
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -42,7 +43,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels", type=int, default=65536, help="channels PER GPU")
     ap.add_argument("--frames", type=int, default=128)
-    ap.add_argument("--mode", choices=["meter", "store", "roundtrip"], default="meter")
+    ap.add_argument("--mode", choices=["meter", "store", "roundtrip", "depayload"], default="meter")
     ap.add_argument("--variant", type=int, default=0, help="0 tuned default, 1 wave-per-frame, 2 chunk32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -127,7 +128,15 @@ def main():
         first = (f * C_total + rank * C_) * n
         ctx.gen_uniform(d_pl[f], C_ * n, first_byte=first, stream=hs)
     d_cd = torch.zeros((C_,), dtype=torch.uint8, device="cuda")           # mu-law (RTP PT 0) everywhere
-    d_out = d_hold = None
+    d_out = d_hold = d_pk = d_radio = d_len = d_info = None
+    if args.mode == "depayload":                                          # [F][C][180] ED-137 packets (header bytes arbitrary but PT 0)
+        d_pk = torch.empty((F_, C_, 180), dtype=torch.uint8, device="cuda")
+        ctx.gen_uniform(d_pk, d_pk.numel(), seed=7, stream=hs)
+        d_pk[:, :, 0] = 0x90
+        d_pk[:, :, 1] = 0
+        d_radio = torch.ones((C_,), dtype=torch.uint8, device="cuda")
+        d_len = torch.empty((F_ * C_,), dtype=torch.int16, device="cuda")
+        d_info = torch.empty((F_ * C_,), dtype=torch.int64, device="cuda")
     if args.mode == "roundtrip":                                          # BASELINE configs[4]: mixed A-law / mu-law
         d_cd[1::2] = 8
         d_out = torch.empty_like(d_pl)
@@ -146,7 +155,9 @@ def main():
         aggs[b].zero_()
         if timer is not None:
             timer.start(hs)
-        if args.mode == "roundtrip":
+        if args.mode == "depayload":
+            ctx.depayload(d_pk, None, d_radio, C_, F_, 180, n, d_pl, d_len, d_info, stream=hs)
+        elif args.mode == "roundtrip":
             ctx.roundtrip_peakhold(d_pl, d_cd, C_, F_, n, d_out, d_st, d_hold, stream=hs)
         else:
             ctx.decode_meter(d_pl, d_cd, C_, F_, n, d_st, pcm=d_pcm, agg=None if args.no_agg else aggs[b], rank=rank, stream=hs)
@@ -192,7 +203,7 @@ def main():
     value = total_samples / dt / 1e6
     bps = BYTES_PER_SAMPLE[args.mode]
     achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9
-    kernel_name = "k_roundtrip_chunk64" if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64")
+    kernel_name = "k_depayload16" if args.mode == "depayload" else "k_roundtrip_chunk64" if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64")
 
     out = {
         "metric": "Msamples/s G.711 decode+RMS, 65536ch@8kHz; %HBM roofline at 1/2/4/8 GPU",

@@ -399,6 +399,18 @@ int igdsp_depayload(igdsp_ctx *ctx, const uint8_t *d_packets, const uint16_t *d_
     return IGDSP_OK;
 }
 
+int igdsp_g726_reorder(igdsp_ctx *ctx, const uint8_t *d_in, uint8_t *d_out, uint64_t n_bytes, int mode, void *stream)
+{
+    if (!ctx || mode < 1 || mode > 4) return IGDSP_EINVAL;
+    if (n_bytes == 0) return IGDSP_OK;
+    if (!d_in || !d_out) return IGDSP_EINVAL;
+    const uint64_t group = (mode == 2) ? 3 : (mode == 4 ? 5 : 1);
+    if (n_bytes % group) return IGDSP_EINVAL;               // the reference over-reads on partial groups
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_g726(cfg_of(ctx), d_in, d_out, n_bytes, mode, pick(ctx, stream)));
+    return IGDSP_OK;
+}
+
 int igdsp_gen_uniform(igdsp_ctx *ctx, uint8_t *d_out, uint64_t n_bytes, uint64_t seed, uint64_t first_byte, void *stream)
 {
     if (!ctx || (!d_out && n_bytes)) return IGDSP_EINVAL;

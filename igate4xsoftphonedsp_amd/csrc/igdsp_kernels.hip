@@ -13,6 +13,13 @@
 
 namespace igdsp {
 
+static inline uint32_t blocks_for(uint64_t items, uint32_t per_block, uint32_t cap)
+{
+    uint64_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (uint32_t)(b > cap ? cap : b);
+}
+
 // ----------------------------------------------------------------------------
 // G.711 expansion magnitude by the ITU segment formula (used to build the LDS
 // tables in-kernel; no table ever comes from host memory).
@@ -930,6 +937,121 @@ __global__ __launch_bounds__(256) void k_depayload_bytes(const uint8_t *__restri
 }
 
 // ============================================================================
+// SURVEY 8(f) rank 4 — G.726 code-word reorder (changeUplinkOrder, roip_ed137.cpp:6379-6499), byte-parallel.
+// Modes 1 / 3 permute bit fields inside each byte: whole dwords with masks, 16 B per lane.
+// Modes 2 / 4 permute inside 3- / 5-byte groups: one lane takes four groups (12 / 20 bytes = 3 / 5 aligned dwords).
+// ============================================================================
+__device__ __forceinline__ uint32_t g726_w2(uint32_t w)   // reverse the four 2-bit fields of each byte
+{
+    return ((w & 0x03030303u) << 6) | ((w & 0x0C0C0C0Cu) << 2) | ((w & 0x30303030u) >> 2) | ((w & 0xC0C0C0C0u) >> 6);
+}
+__device__ __forceinline__ uint32_t g726_w4(uint32_t w) { return ((w >> 4) & 0x0F0F0F0Fu) | ((w << 4) & 0xF0F0F0F0u); }
+
+__device__ __forceinline__ uint32_t g726_g3(uint32_t V)   // 24-bit group, reference field layout
+{
+    const uint32_t S1 = V & 7u, S2 = (V >> 3) & 7u, S3 = (V >> 7) & 3u, S3_ = (V >> 6) & 1u, S4 = (V >> 9) & 7u;
+    const uint32_t S5 = (V >> 12) & 7u, S6 = (V >> 17) & 1u, S6_ = (V >> 15) & 3u, S7 = (V >> 18) & 7u, S8 = (V >> 21) & 7u;
+    return (S3 | (S2 << 2) | (S1 << 5)) | ((S6 | (S5 << 1) | (S4 << 4) | (S3_ << 7)) << 8) | ((S8 | (S7 << 3) | (S6_ << 6)) << 16);
+}
+
+__device__ __forceinline__ void g726_g5(const uint32_t t0, const uint32_t t1, const uint32_t t2, const uint32_t t3, const uint32_t t4,
+                                        uint32_t (&o)[5])
+{
+    const uint32_t S1 = t0 & 0x1Fu, S2 = ((t1 << 1) | (t0 >> 7)) & 7u;      // S2_ (2-bit field <- 0 or 4) is always 0 in the reference
+    const uint32_t S3 = (t1 >> 2) & 0x1Fu, S4 = (t2 >> 3) & 1u, S4_ = ((t2 << 1) | (t1 >> 7)) & 0x0Fu;
+    const uint32_t S5 = ((t3 << 3) | (t2 >> 5)) & 0x0Fu, S5_ = (t2 >> 4) & 1u, S6 = (t3 >> 1) & 0x1Fu;
+    const uint32_t S7 = (t4 >> 1) & 3u, S7_ = ((t4 << 2) | (t3 >> 6)) & 7u, S8 = (t4 >> 3) & 0x1Fu;
+    o[0] = S2 | (S1 << 3); o[1] = S4 | (S3 << 1); o[2] = S5 | (S4_ << 4); o[3] = S7 | (S6 << 2) | (S5_ << 7); o[4] = S8 | (S7_ << 5);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_g726_bytes(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint64_t n_units)
+{
+    // unit = 16 bytes (modes 1, 3), 12 bytes (mode 2), 20 bytes (mode 4); all dword aligned
+    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units; u += (uint64_t)gridDim.x * blockDim.x) {
+        if (MODE == 1 || MODE == 3) {
+            const uint4 d = ld_stream(reinterpret_cast<const uint4 *>(in) + u);
+            uint4 r;
+            if (MODE == 1) r = make_uint4(g726_w2(d.x), g726_w2(d.y), g726_w2(d.z), g726_w2(d.w));
+            else r = make_uint4(g726_w4(d.x), g726_w4(d.y), g726_w4(d.z), g726_w4(d.w));
+            reinterpret_cast<uint4 *>(out)[u] = r;
+        } else if (MODE == 2) {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(in) + u * 3u;
+            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+            const uint32_t r0 = g726_g3(d0 & 0xFFFFFFu), r1 = g726_g3((d0 >> 24) | ((d1 & 0xFFFFu) << 8));
+            const uint32_t r2 = g726_g3((d1 >> 16) | ((d2 & 0xFFu) << 16)), r3 = g726_g3(d2 >> 8);
+            uint32_t *q = reinterpret_cast<uint32_t *>(out) + u * 3u;
+            q[0] = r0 | (r1 << 24); q[1] = (r1 >> 8) | (r2 << 16); q[2] = (r2 >> 16) | (r3 << 8);
+        } else {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(in) + u * 5u;
+            uint32_t d[5], b[20], r[20];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) d[i] = p[i];
+#pragma unroll
+            for (int i = 0; i < 20; ++i) b[i] = (d[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint32_t o[5];
+                g726_g5(b[5 * g], b[5 * g + 1], b[5 * g + 2], b[5 * g + 3], b[5 * g + 4], o);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) r[5 * g + i] = o[i];
+            }
+            uint32_t *q = reinterpret_cast<uint32_t *>(out) + u * 5u;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) q[i] = r[4 * i] | (r[4 * i + 1] << 8) | (r[4 * i + 2] << 16) | (r[4 * i + 3] << 24);
+        }
+    }
+}
+
+// tail / unaligned: one lane per group of 1, 3 or 5 bytes
+template <int MODE>
+__global__ __launch_bounds__(256) void k_g726_groups(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint64_t first_byte,
+                                                     uint64_t n_groups)
+{
+    constexpr uint32_t G = (MODE == 2) ? 3u : (MODE == 4 ? 5u : 1u);
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint8_t *p = in + first_byte + g * G;
+        uint8_t *q = out + first_byte + g * G;
+        if (MODE == 1) q[0] = (uint8_t)g726_w2(p[0]);
+        else if (MODE == 3) q[0] = (uint8_t)g726_w4(p[0]);
+        else if (MODE == 2) {
+            const uint32_t r = g726_g3((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16));
+            q[0] = (uint8_t)r; q[1] = (uint8_t)(r >> 8); q[2] = (uint8_t)(r >> 16);
+        } else {
+            uint32_t o[5];
+            g726_g5(p[0], p[1], p[2], p[3], p[4], o);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) q[i] = (uint8_t)o[i];
+        }
+    }
+}
+
+template <int MODE>
+static hipError_t launch_g726_mode(const LaunchCfg &cfg, const uint8_t *in, uint8_t *out, uint64_t n_bytes, hipStream_t s)
+{
+    constexpr uint64_t G = (MODE == 2) ? 3 : (MODE == 4 ? 5 : 1);
+    constexpr uint64_t U = (MODE == 2) ? 12 : (MODE == 4 ? 20 : 16);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0u;
+    const uint64_t units = aligned ? n_bytes / U : 0;
+    const uint32_t cap = (uint32_t)cfg.compute_units * 8u;
+    if (units) hipLaunchKernelGGL((k_g726_bytes<MODE>), dim3(blocks_for(units, 256, cap)), dim3(256), 0, s, in, out, units);
+    const uint64_t rest = n_bytes - units * U;
+    if (rest) hipLaunchKernelGGL((k_g726_groups<MODE>), dim3(blocks_for(rest / G, 256, cap)), dim3(256), 0, s, in, out, units * U, rest / G);
+    return hipGetLastError();
+}
+
+hipError_t launch_g726(const LaunchCfg &cfg, const uint8_t *in, uint8_t *out, uint64_t n_bytes, int mode, hipStream_t s)
+{
+    if (n_bytes == 0) return hipSuccess;
+    switch (mode) {
+    case 1: return launch_g726_mode<1>(cfg, in, out, n_bytes, s);
+    case 2: return launch_g726_mode<2>(cfg, in, out, n_bytes, s);
+    case 3: return launch_g726_mode<3>(cfg, in, out, n_bytes, s);
+    default: return launch_g726_mode<4>(cfg, in, out, n_bytes, s);
+    }
+}
+
+// ============================================================================
 // Synthetic D-uniform generator: 8 bytes per splitmix64 word.
 // ============================================================================
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
@@ -988,12 +1110,6 @@ __global__ __launch_bounds__(kBlockThreads) void k_stream_read(const uint4 *__re
 // ============================================================================
 // launchers
 // ============================================================================
-static inline uint32_t blocks_for(uint64_t items, uint32_t per_block, uint32_t cap)
-{
-    uint64_t b = (items + per_block - 1) / per_block;
-    if (b < 1) b = 1;
-    return (uint32_t)(b > cap ? cap : b);
-}
 
 hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t *payload, const uint8_t *codec,
                                const uint16_t *len, uint32_t C, uint32_t F, uint32_t n, igdsp_frame_stats *stats,

@@ -263,6 +263,17 @@ int igdsp_depayload(igdsp_ctx *ctx, const uint8_t *d_packets, const uint16_t *d_
                     uint32_t n_channels, uint32_t n_frames, uint32_t pkt_stride, uint32_t samples_per_frame,
                     uint8_t *d_payload_out, uint16_t *d_len_out, igdsp_rtp_info *d_info_out, void *stream);
 
+/* ---- G.726 code-word reorder (RoIP_ED137::changeUplinkOrder, roip_ed137.cpp:6379-6499) ----
+ * Repacks G.726 code words between the RFC 3551 and AAL2 bit orders, bug-for-bug as the reference
+ * does it on its (unsigned-char) target:
+ *   mode 1 (16 kbit/s, 2-bit): the four 2-bit fields of every byte are reversed          (:6382-6389)
+ *   mode 2 (24 kbit/s, 3-bit): 3-byte groups through the reference's bit-field struct   (:6390-6441)
+ *   mode 3 (32 kbit/s, 4-bit): nibbles swapped                                           (:6442-6449)
+ *   mode 4 (40 kbit/s, 5-bit): 5-byte groups; the reference's 2-bit field S2_ receives
+ *          `(b0 >> 5) & 0x04`, which never fits, so those two output bits are always 0  (:6450-6498)
+ * n_bytes must be a multiple of the group size (1, 3, 1, 5): the reference over-reads otherwise. */
+int igdsp_g726_reorder(igdsp_ctx *ctx, const uint8_t *d_in, uint8_t *d_out, uint64_t n_bytes, int g726UplinkBitrate, void *stream);
+
 /* ---- synthetic input generators (device side; SURVEY 8(d) definitions) ---------
  * D-uniform: byte k of global byte index g is
  *   (splitmix64(seed + (g>>3)) >> (8*(g&7))) & 0xFF,  g = first_byte + k

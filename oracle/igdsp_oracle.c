@@ -239,6 +239,49 @@ void orc_roundtrip_peakhold(const uint8_t *payload, const uint8_t *codec, uint32
 }
 
 /* ------------------------------------------------------------------------- */
+/* changeUplinkOrder (roip_ed137.cpp:6379-6499).  The reference fills packed   */
+/* bit-field structs (GCC allocates fields from the least significant bit) and */
+/* memcpy()s them out; here every output byte is written as the OR of its      */
+/* fields at their bit positions.  `Input` is `const char*` = unsigned on the  */
+/* product target.  Mode 4's S2_ is a 2-bit field assigned (b0 >> 5) & 0x04 —  */
+/* the value 4 does not fit, so the field is always 0 (kept: bug-for-bug).     */
+/* ------------------------------------------------------------------------- */
+void orc_g726_reorder(const uint8_t *in, uint8_t *out, size_t n, int mode)
+{
+    if (mode == 1) {
+        for (size_t k = 0; k < n; ++k) {
+            unsigned b = in[k];
+            out[k] = (uint8_t)((b << 6) | (b >> 6) | ((b & 0x30) >> 2) | ((b & 0x0C) << 2));
+        }
+    } else if (mode == 3) {
+        for (size_t k = 0; k < n; ++k) { unsigned b = in[k]; out[k] = (uint8_t)((b >> 4) | (b << 4)); }
+    } else if (mode == 2) {
+        for (size_t o = 0; o + 3 <= n; o += 3) {
+            unsigned V = (unsigned)in[o] | ((unsigned)in[o + 1] << 8) | ((unsigned)in[o + 2] << 16);
+            unsigned S1 = V & 7, S2 = (V >> 3) & 7, S3 = (V >> 7) & 3, S3_ = (V >> 6) & 1, S4 = (V >> 9) & 7;
+            unsigned S5 = (V >> 12) & 7, S6 = (V >> 17) & 1, S6_ = (V >> 15) & 3, S7 = (V >> 18) & 7, S8 = (V >> 21) & 7;
+            out[o] = (uint8_t)(S3 | (S2 << 2) | (S1 << 5));             /* S3:2 S2:3 S1:3 */
+            out[o + 1] = (uint8_t)(S6 | (S5 << 1) | (S4 << 4) | (S3_ << 7)); /* S6:1 S5:3 S4:3 S3_:1 */
+            out[o + 2] = (uint8_t)(S8 | (S7 << 3) | (S6_ << 6));        /* S8:3 S7:3 S6_:2 */
+        }
+    } else if (mode == 4) {
+        for (size_t o = 0; o + 5 <= n; o += 5) {
+            unsigned t0 = in[o], t1 = in[o + 1], t2 = in[o + 2], t3 = in[o + 3], t4 = in[o + 4];
+            unsigned S1 = t0 & 0x1F, S2 = ((t1 << 1) | (t0 >> 7)) & 0x07;
+            unsigned S2_ = ((t0 >> 5) & 0x04) & 0x03;                     /* 2-bit field: always 0 */
+            unsigned S3 = (t1 >> 2) & 0x1F, S4 = (t2 >> 3) & 0x01, S4_ = ((t2 << 1) | (t1 >> 7)) & 0x0F;
+            unsigned S5 = ((t3 << 3) | (t2 >> 5)) & 0x0F, S5_ = (t2 >> 4) & 0x01, S6 = (t3 >> 1) & 0x1F;
+            unsigned S7 = (t4 >> 1) & 0x03, S7_ = ((t4 << 2) | (t3 >> 6)) & 0x07, S8 = (t4 >> 3) & 0x1F;
+            out[o] = (uint8_t)(S2 | (S1 << 3));                          /* S2:3 S1:5 */
+            out[o + 1] = (uint8_t)(S4 | (S3 << 1) | (S2_ << 6));        /* S4:1 S3:5 S2_:2 */
+            out[o + 2] = (uint8_t)(S5 | (S4_ << 4));                    /* S5:4 S4_:4 */
+            out[o + 3] = (uint8_t)(S7 | (S6 << 2) | (S5_ << 7));        /* S7:2 S6:5 S5_:1 */
+            out[o + 4] = (uint8_t)(S8 | (S7_ << 5));                    /* S8:5 S7_:3 */
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* transport_rtp_cb (TransportAdapter.cpp:240-292): the header is the first    */
 /* 12 bytes (plain SIP) or 20 bytes (radio: custom_rtp_hdr, ed137_rtp.h:22-48) */
 /* of the packet; payloadlen = size - header; PT is the low 7 bits of byte 1;  */

@@ -72,6 +72,9 @@ typedef struct { uint32_t ed137; uint16_t payload_len; uint8_t pt; uint8_t flags
 void orc_depayload(const uint8_t *packets, const uint16_t *sizes, const uint8_t *radio, uint32_t C, uint32_t F,
                    uint32_t stride, uint32_t n, uint8_t *payload, uint16_t *len, orc_rtp_info *info);
 
+/* roip_ed137.cpp:6379-6499 changeUplinkOrder restated (unsigned-char target, GCC LSB-first bit-fields) */
+void orc_g726_reorder(const uint8_t *in, uint8_t *out, size_t n, int mode);
+
 /* synthetic data */
 uint64_t orc_splitmix64(uint64_t x);
 void orc_gen_uniform(uint8_t *out, uint64_t n_bytes, uint64_t seed, uint64_t first_byte);

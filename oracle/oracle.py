@@ -83,6 +83,7 @@ def lib() -> C.CDLL:
         L.orc_roundtrip_peakhold.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_int]
         L.orc_depayload.restype = None
         L.orc_depayload.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
+        L.orc_g726_reorder.restype = None; L.orc_g726_reorder.argtypes = [vp, vp, C.c_size_t, C.c_int]
         L.orc_splitmix64.restype = C.c_uint64; L.orc_splitmix64.argtypes = [C.c_uint64]
         L.orc_gen_uniform.restype = None; L.orc_gen_uniform.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64]
         L.orc_gen_speech.restype = None
@@ -198,6 +199,13 @@ def depayload(packets, sizes, radio, n=160):
     info = np.zeros((F_, C_), RTP_INFO)
     lib().orc_depayload(_p(packets), _p(sizes), _p(radio), C_, F_, stride, n, _p(payload), _p(ln), _p(info))
     return payload, ln, info
+
+
+def g726_reorder(data: np.ndarray, mode: int) -> np.ndarray:
+    data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+    out = np.zeros_like(data)
+    lib().orc_g726_reorder(_p(data), _p(out), data.size, mode)
+    return out
 
 
 def byte_mean(buf: bytes | np.ndarray, signed_char=False) -> int:
