@@ -399,14 +399,22 @@ __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half
         bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
         sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
         sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
+#ifndef IGDSP_AB_NOMAX
         peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
         peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
+#else
+        peak |= e[k][0].y;   // diagnostic build only: drops 3 of 4 max3 per unit (results wrong)
+#endif
         if (STORE_PCM) {
             o[4 * k + 0] = pack_pcm(wa[k], 0, e[k][0].y, e[k][1].y); o[4 * k + 1] = pack_pcm(wa[k], 2, e[k][2].y, e[k][3].y);
             o[4 * k + 2] = pack_pcm(wb[k], 0, e[k][4].y, e[k][5].y); o[4 * k + 3] = pack_pcm(wb[k], 2, e[k][6].y, e[k][7].y);
         }
         if (k == 1) {                           // piece j complete
+#ifndef IGDSP_AB_NOPROBE
             strip_half[j * 64 + lane] = make_uint2(sum, peak | (bsum << 16) | probe_fail(d[j], pm[j]));
+#else
+            strip_half[j * 64 + lane] = make_uint2(sum, peak | (bsum << 16));   // diagnostic build only
+#endif
             if (STORE_PCM) {
                 // Each lane holds 32 contiguous PCM bytes (A = o[0..3], B = o[4..7]); four neighbouring lanes hold
                 // 128.  A quad-local DPP shuffle regroups them so that one store instruction writes 64 contiguous
@@ -558,7 +566,14 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
                     fail |= v.y | v.w;
                 }
                 uint32_t bm, fl;
+#ifndef IGDSP_AB_NOSTORE
                 st_stream(reinterpret_cast<uint4 *>(stats + (f0 + lane)), pack_stats160(s, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl));
+#else
+                {   // diagnostic build only: keep the math alive, store one record per launch
+                    const uint4 r = pack_stats160(s, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl);
+                    if (r.x == 0x12345678u && r.y == 0x9ABCDEF0u) st_stream(reinterpret_cast<uint4 *>(stats + (f0 + lane)), r);
+                }
+#endif
                 if (AGG) {
                     a_sumsq += s << 4; a_frames += 1u; a_sil += (fl & IGDSP_FLAG_SILENT) ? 1u : 0u;
                     a_clip += (fl & IGDSP_FLAG_CLIPPED) ? 1u : 0u; a_bm += bm; a_peak = max(a_peak, peak);
