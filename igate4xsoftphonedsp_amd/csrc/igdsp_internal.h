@@ -20,6 +20,8 @@ constexpr int kBlockThreads = kWavesPerBlock * 64;
 
 struct LaunchCfg {
     int compute_units;   // persistent grid = compute_units blocks
+    uint32_t *gqueue;    // device-wide work counter {next batch, blocks done} for this launch, zero on entry
+                         // and re-armed by the kernel itself; nullptr = static per-block distribution
 };
 
 hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant,

@@ -11,6 +11,8 @@
 //   hold / window aggregate       : Functions.cpp:2126-2145, 2155-2167.
 #include "igdsp_internal.h"
 
+#include <cstdlib>
+
 namespace igdsp {
 
 static inline uint32_t blocks_for(uint64_t items, uint32_t per_block, uint32_t cap)
@@ -471,15 +473,29 @@ template <bool STORE_PCM, bool AGG, bool DIAG = false>
 __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chunk64(
     const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t n_frames,
     igdsp_frame_stats *__restrict__ stats, int16_t *__restrict__ pcm, igdsp_aggregate *agg, uint32_t rank,
-    uint64_t *__restrict__ diag = nullptr)
+    uint64_t *__restrict__ diag = nullptr, uint32_t *__restrict__ gqueue = nullptr)
 {
     constexpr int kWaves = ChunkGeom<STORE_PCM>::kWaves;
     __shared__ uint2 lds[kLutEntries + kWaves * kStripEntries];   // 64 KiB LUT + 5 KiB strip per wave
-    __shared__ uint32_t next_item;
+    // Work queue.  A *batch* = kWaves consecutive super-chunks.  The block's first batch is static (its
+    // blockIdx); further batches come from ONE device-wide counter (gqueue[0], one atomic per batch, i.e.
+    // per ~160 KiB of input), so fast CUs take more and the launch has no inter-CU tail.  Inside the block
+    // the waves draw slots from an LDS counter; the wave that draws the first slot of local batch j
+    // prefetches the id of batch j+1, so nobody waits for the device atomic's latency.
+    constexpr int kRing = 8;
+    __shared__ uint32_t q_next, q_batch[kRing], q_tag[kRing];
     uint64_t d_t0 = 0, d_t1 = 0, d_iter = 0, d_rt0 = 0, d_setup = 0, d_px = 0, d_py = 0, d_red = 0;
     if (DIAG) { d_t0 = now_cycles(); d_rt0 = __builtin_amdgcn_s_memrealtime(); }
+    const uint32_t G = gridDim.x;
+    uint32_t gb1 = 0;
+    if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);   // id of this block's 2nd batch; lands under the LUT fill
     fill_lut(lds);
-    if (threadIdx.x == 0) next_item = kWaves;                    // items 0..kWaves-1 are the waves' first picks
+    if (threadIdx.x == 0) {
+        q_next = kWaves;                                         // slots 0..kWaves-1 = the waves' first picks
+        for (int i = 0; i < kRing; ++i) q_tag[i] = 0xFFFFFFFFu;
+        q_batch[0] = blockIdx.x; q_tag[0] = 0u;
+        q_batch[1] = gqueue ? gb1 + G : blockIdx.x + G; q_tag[1] = 1u;
+    }
     __syncthreads();
     if (DIAG) d_t1 = now_cycles();
 
@@ -495,7 +511,6 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
         pm[j] = probe_mask(p - fr[j] * 10u);
     }
 
-    const uint32_t G = gridDim.x;
     const uint32_t n_super = n_frames / kSuperFrames;             // the launcher hands over whole super-chunks only:
     const uint4 *src16 = reinterpret_cast<const uint4 *>(payload); // no tail predicate anywhere in the loop
 
@@ -511,25 +526,35 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
         const uint32_t c = (sidx * (uint32_t)kSuperFrames + lane) % C;     // < 2^32: the ABI caps C*F
         return (uint32_t)codec[c];
     };
-    auto grab = [&]() {                                          // next item of this block (wave-uniform)
-        uint32_t k = 0;
-        if (lane == 0) k = atomicAdd(&next_item, 1u);
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    auto grab = [&]() -> uint32_t {                              // next super-chunk for this wave (wave-uniform)
+        uint32_t v = 0;
+        if (lane == 0) {
+            const uint32_t s = atomicAdd(&q_next, 1u);
+            const uint32_t j = s / (uint32_t)kWaves, w = s - j * (uint32_t)kWaves;
+            if (w == 0u) {                                       // first drawer of local batch j announces batch j + 1
+                const uint32_t nb = gqueue ? atomicAdd(gqueue, 1u) + G : blockIdx.x + (j + 1u) * G;
+                __hip_atomic_store(&q_batch[(j + 1u) % kRing], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&q_tag[(j + 1u) % kRing], j + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            while (__hip_atomic_load(&q_tag[j % kRing], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j)
+                __builtin_amdgcn_s_sleep(2);                     // published by a wave of this block that never waits on us
+            v = __hip_atomic_load(&q_batch[j % kRing], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * (uint32_t)kWaves + w;
+        }
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     };
 
-    uint32_t sidx = blockIdx.x + wave * G;
+    uint32_t sidx = blockIdx.x * (uint32_t)kWaves + wave;        // batch blockIdx.x, slot = wave
     if (sidx < n_super) {
         uint4 X[kLoadsPerChunk], Y[kLoadsPerChunk];
         uint32_t cur_pt = fetch_pt(sidx);          // issue order pt, X, Y — the same in the prologue and in the loop,
         fetch_half(X, sidx, 0);                    // so the waits at the loop head stay counted (vmcnt(N), not 0)
         fetch_half(Y, sidx, 1);
-        uint32_t k_next = grab();                  // the item after this one (pulled one iteration ahead of use)
+        uint32_t s_next = grab();                  // the item after this one (pulled one iteration ahead of use)
         for (;;) {
             uint64_t d_a = 0, d_b = 0, d_c = 0, d_d = 0;
             if (DIAG) d_a = now_cycles();
-            const uint32_t s_next = blockIdx.x + k_next * G;
             const bool has_next = s_next < n_super;
-            const uint32_t s_load = has_next ? s_next : sidx;    // last round: harmless re-read (cache hit), keeps loads unconditional
+            const uint32_t s_load = has_next ? s_next : 0u;      // last round: every wave re-reads super-chunk 0 (L2-hot), loads stay unconditional
             const uint32_t f0 = sidx * kSuperFrames;
             // law of frame l of this super-chunk lives in lane l; one ballot turns it into a 64-bit wave mask,
             // and each piece picks its frame's bit (no cross-lane traffic per piece)
@@ -550,8 +575,11 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
             if (DIAG) d_c = now_cycles();
             process_half<STORE_PCM>(lds, strip + kPiecesPerChunk, Y, lm1, pm, off, lane, pcm16 + 2 * kPiecesPerChunk, nsrc + kPiecesPerChunk);
             if (DIAG) d_d = now_cycles();
-            if (has_next) k_next = grab();         // its LDS round trip hides under the frame fold below
+            const uint32_t s_after = has_next ? grab() : 0xFFFFFFFFu;   // its LDS round trip hides under the frame fold below
 
+#ifdef IGDSP_AB_PRIO
+            __builtin_amdgcn_s_setprio(IGDSP_AB_PRIO);
+#endif
             wave_lds_fence();
             {
                 const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kPiecesPerFrame);   // 80 B rows, 16 B aligned
@@ -580,11 +608,19 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
                 }
             }
             wave_lds_fence();
+#ifdef IGDSP_AB_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             if (DIAG) { d_iter += 1; d_setup += d_b - d_a; d_px += d_c - d_b; d_py += d_d - d_c; d_red += now_cycles() - d_d; }
             if (!has_next) break;
             sidx = s_next;
+            s_next = s_after;
             cur_pt = nxt_pt;
         }
+    }
+    if (gqueue != nullptr) {                   // the last block out re-arms the device counter for the next launch
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(gqueue + 1, 1u) == G - 1u) { gqueue[0] = 0u; gqueue[1] = 0u; }
     }
     if (DIAG && lane == 0 && diag != nullptr) {
         uint64_t *o = diag + (uint64_t)(blockIdx.x * kWaves + wave) * 12u;
@@ -1122,6 +1158,27 @@ __global__ __launch_bounds__(kBlockThreads) void k_stream_read(const uint4 *__re
     if ((threadIdx.x & 63u) == 0u && v == 0x9E3779B9u) atomicAdd((unsigned long long *)sink, 1ull);   // keeps the loads live
 }
 
+// Same calibration with the meter kernel's exact access pattern: a wave owns a 10 KiB contiguous
+// super-chunk (ten 1 KiB loads), 16 waves per block take 16 adjacent super-chunks, blocks stride by G.
+__global__ __launch_bounds__(kBlockThreads) void k_stream_read_chunked(const uint4 *__restrict__ src, uint32_t n_super,
+                                                                       uint64_t *__restrict__ sink)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (uint32_t b = blockIdx.x; b * kWavesPerBlock + wave < n_super; b += gridDim.x) {
+        const uint4 *p = src + ((uint64_t)(b * kWavesPerBlock + wave) * 640u + lane);
+        uint4 v[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = ld_stream(p + j * 64);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) { acc.x ^= v[j].x; acc.y ^= v[j].y; acc.z ^= v[j].z; acc.w ^= v[j].w; }
+    }
+    uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) r ^= (uint32_t)__shfl_xor((int)r, m, 64);
+    if (lane == 0u && r == 0x9E3779B9u) atomicAdd((unsigned long long *)sink, 1ull);
+}
+
 // ============================================================================
 // launchers
 // ============================================================================
@@ -1130,6 +1187,7 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
                                const uint16_t *len, uint32_t C, uint32_t F, uint32_t n, igdsp_frame_stats *stats,
                                int16_t *pcm, igdsp_aggregate *agg, uint32_t rank, hipStream_t s)
 {
+    uint32_t *gq = cfg.gqueue;
     const uint64_t n_frames64 = (uint64_t)C * F;
     if (n_frames64 == 0) return hipSuccess;
     const uint32_t n_frames = (uint32_t)n_frames64;
@@ -1147,12 +1205,12 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
         if (pcm) {
             constexpr int w = ChunkGeom<true>::kWaves;
             const uint32_t grid = blocks_for(n_super, w, (uint32_t)cfg.compute_units);
-            if (agg) hipLaunchKernelGGL((k_meter_chunk64<true, true>), dim3(grid), dim3(w * 64), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag);
-            else     hipLaunchKernelGGL((k_meter_chunk64<true, false>), dim3(grid), dim3(w * 64), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag);
+            if (agg) hipLaunchKernelGGL((k_meter_chunk64<true, true>), dim3(grid), dim3(w * 64), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag, gq);
+            else     hipLaunchKernelGGL((k_meter_chunk64<true, false>), dim3(grid), dim3(w * 64), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag, gq);
         } else {
             const uint32_t grid = blocks_for(n_super, kWavesPerBlock, (uint32_t)cfg.compute_units);
-            if (agg) hipLaunchKernelGGL((k_meter_chunk64<false, true>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag);
-            else     hipLaunchKernelGGL((k_meter_chunk64<false, false>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag);
+            if (agg) hipLaunchKernelGGL((k_meter_chunk64<false, true>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag, gq);
+            else     hipLaunchKernelGGL((k_meter_chunk64<false, false>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, done, stats, pcm, agg, rank, nodiag, gq);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -1171,7 +1229,7 @@ hipError_t launch_diag_chunk32(const LaunchCfg &cfg, const uint8_t *payload, con
     const uint32_t n_frames = n_super * kSuperFrames;
     const uint32_t grid = blocks_for(n_super, kWavesPerBlock, (uint32_t)cfg.compute_units);
     hipLaunchKernelGGL((k_meter_chunk64<false, false, true>), dim3(grid), dim3(kBlockThreads), 0, s, payload, codec, C, n_frames,
-                       stats, (int16_t *)nullptr, (igdsp_aggregate *)nullptr, 0u, diag);
+                       stats, (int16_t *)nullptr, (igdsp_aggregate *)nullptr, 0u, diag, cfg.gqueue);
     return hipGetLastError();
 }
 
@@ -1250,6 +1308,13 @@ hipError_t launch_gen_uniform(uint8_t *out, uint64_t n_bytes, uint64_t seed, uin
 hipError_t launch_stream_read(const LaunchCfg &cfg, const void *src, size_t bytes, uint64_t *sink, hipStream_t s)
 {
     if (bytes < 16) return hipSuccess;
+    if (const char *e = getenv("IGDSP_STREAM_MODE")) {
+        if (atoi(e) == 1) {
+            hipLaunchKernelGGL(k_stream_read_chunked, dim3(cfg.compute_units), dim3(kBlockThreads), 0, s,
+                               reinterpret_cast<const uint4 *>(src), (uint32_t)(bytes / 10240u), sink);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(k_stream_read, dim3(cfg.compute_units), dim3(kBlockThreads), 0, s,
                        reinterpret_cast<const uint4 *>(src), (uint64_t)(bytes >> 4), sink);
     return hipGetLastError();
