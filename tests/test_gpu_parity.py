@@ -417,3 +417,37 @@ def test_full_size_roundtrip_idempotence_config5(ctx, big, orc):
         e = orc.decode_meter(pl.reshape(1, 1, n), [int(codec[c])])[0, 0]
         assert (int(st[f, c]["sumsq"]), int(st[f, c]["peak"]), int(st[f, c]["byte_mean"])) == \
                (int(e["sumsq"]), int(e["peak"]), int(e["byte_mean"]))
+
+
+# ----------------------------------------------------------------------------- randomized shapes
+def test_fuzz_shapes_against_oracle(ctx, orc):
+    """120 random (C, F, n, law mix, ragged?, pcm?, agg?) cases, incl. the 64-frame super-chunk boundary,
+    channel wrap inside a super-chunk and tails handed to the general kernel."""
+    rng = np.random.default_rng(20241218)
+    for case in range(120):
+        n = int(rng.choice([160, 160, 160, 160, 24, 164, 96, 255, 1]))
+        C_ = int(rng.choice([1, 3, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200]))
+        F_ = int(rng.integers(1, 9))
+        if rng.integers(0, 4) == 0:
+            C_, F_ = int(rng.integers(60, 700)), int(rng.integers(1, 4))
+        ragged = n != 160 and rng.integers(0, 2) == 1
+        want_pcm, want_agg = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        payload = orc.gen_uniform(F_ * C_ * n, seed=1000 + case).reshape(F_, C_, n).copy()
+        if rng.integers(0, 3) == 0:                                   # digital silence / full scale rows
+            payload[rng.integers(0, F_), rng.integers(0, C_)] = rng.choice([0xFF, 0xD5, 0x00, 0x2A, 0x7F])
+        codec = rng.choice(np.array([0, 8], np.uint8), size=C_)
+        length = rng.integers(0, n + 1, size=(F_, C_)).astype(np.uint16) if ragged else None
+        ctx.set_variant(int(rng.choice([0, 0, 1])))
+        st, pcm, agg = gu.run_decode_meter(ctx, payload, codec, length=length, want_pcm=want_pcm, want_agg=want_agg, rank=case % 8)
+        res = orc.decode_meter(payload, codec, length=length, want_pcm=want_pcm, want_agg=want_agg, rank=case % 8)
+        res = res if isinstance(res, tuple) else (res,)
+        gu.assert_stats_equal(st, res[0], n=length if ragged else n)
+        k = 1
+        if want_pcm:
+            assert np.array_equal(pcm, res[k]), case
+            k += 1
+        if want_agg:
+            for f in ("sumsq", "samples", "frames", "n_silent", "n_clipped", "byte_mean_sum"):
+                assert int(agg[f]) == int(res[k][f]), (case, f)
+            assert agg["peak_slot"].tolist() == res[k]["peak_slot"].tolist(), case
+    ctx.set_variant(0)
