@@ -154,6 +154,23 @@ __device__ __forceinline__ igdsp_frame_stats make_stats(uint64_t sumsq, uint32_t
     return st;
 }
 
+// Wave64 reductions on the VALU's DPP path (no LDS round trips): an inclusive scan inside each row of 16
+// lanes (row_shr 1/2/4/8), then row_bcast15 / row_bcast31 carry the row totals upward; lane 63 ends up
+// with the wave total and is read out with v_readlane.  Identity 0 suits unsigned add and max.
+template <typename Op>
+__device__ __forceinline__ uint32_t wave_reduce_dpp(uint32_t v, Op op)
+{
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));   // row_shr:2
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));   // row_shr:4
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));   // row_shr:8
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+struct OpAdd { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
+struct OpMax { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return max(a, b); } };
+
 // ============================================================================
 // Variant 1 — the literal north_star mapping: ONE wavefront per channel-frame.
 // Lane l owns bytes [4l, 4l+4) of the frame (n <= 256 => <= 64 lanes; n = 160
@@ -182,11 +199,7 @@ __global__ __launch_bounds__(256) void k_meter_wave_per_frame(
     uint64_t a_sumsq = 0, a_samples = 0;
     uint32_t a_frames = 0, a_sil = 0, a_clip = 0, a_bm = 0, a_peak = 0;
 
-    for (uint32_t fi = first_frame + blockIdx.x * 4u + wave; fi < n_frames; fi += gridDim.x * 4u) {
-        const uint32_t c = fi % C;
-        const bool alaw = codec[c] == IGDSP_PT_PCMA;
-        uint32_t l = len ? (uint32_t)len[fi] : n;
-        l = min(l, n);
+    auto load_frame = [&](uint32_t fi) -> uint32_t {                 // this lane's four payload bytes of frame fi
         const uint8_t *base = payload + (uint64_t)fi * n;
         const uint32_t b0 = lane * 4u;
         uint32_t w = 0;
@@ -197,8 +210,16 @@ __global__ __launch_bounds__(256) void k_meter_wave_per_frame(
             for (uint32_t k = 0; k < 4u; ++k)
                 if (b0 + k < n) w |= (uint32_t)base[b0 + k] << (8u * k);
         }
+        return w;
+    };
+    auto process_frame = [&](uint32_t fi, uint32_t w) {
+        const uint32_t c = fi % C;
+        const bool alaw = codec[c] == IGDSP_PT_PCMA;
+        uint32_t l = len ? (uint32_t)len[fi] : n;
+        l = min(l, n);
+        const uint32_t b0 = lane * 4u;
         const uint32_t nvalid = (l > b0) ? min(l - b0, 4u) : 0u;
-        uint32_t sum = 0, peak = 0, bsum = 0;   // 4 * 32256^2 = 4.16e9 < 2^32
+        uint32_t sum = 0, peak = 0, bsum = 0;   // sum of (|x|/4)^2: 4 * 8064^2 = 2.6e8 per lane
         int x[4];
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) {
@@ -207,7 +228,7 @@ __global__ __launch_bounds__(256) void k_meter_wave_per_frame(
             if (k >= nvalid) v = 0;
             x[k] = v;
             const uint32_t ax = (uint32_t)(v < 0 ? -v : v);
-            sum += ax * ax;
+            sum += (ax >> 2) * (ax >> 2);        // every G.711 magnitude is a multiple of 4
             peak = max(peak, ax);
             bsum += (k < nvalid) ? b : 0u;
         }
@@ -225,16 +246,14 @@ __global__ __launch_bounds__(256) void k_meter_wave_per_frame(
             }
         }
         // reference silence probe: payload bytes 28 / 38 / 48 (lanes 7, 9, 12)
-        const uint32_t w7 = (uint32_t)__shfl((int)w, 7, 64), w9 = (uint32_t)__shfl((int)w, 9, 64),
-                       w12 = (uint32_t)__shfl((int)w, 12, 64);
+        const uint32_t w7 = (uint32_t)__builtin_amdgcn_readlane((int)w, 7), w9 = (uint32_t)__builtin_amdgcn_readlane((int)w, 9),
+                       w12 = (uint32_t)__builtin_amdgcn_readlane((int)w, 12);
         const bool probe = (l > 48u) && ((w7 & 255u) == 0xD5u) && (((w9 >> 16) & 255u) == 0xD5u) && ((w12 & 255u) == 0xD5u);
-        uint64_t s64 = sum;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            s64 += shfl_xor_u64(s64, m);
-            peak = max(peak, (uint32_t)__shfl_xor((int)peak, m, 64));
-            bsum += (uint32_t)__shfl_xor((int)bsum, m, 64);
-        }
+        // wavefront shuffle-reduce: the 38-bit sum travels as two 32-bit halves (low 16 bits / rest)
+        const uint32_t r_lo = wave_reduce_dpp(sum & 0xFFFFu, OpAdd()), r_hi = wave_reduce_dpp(sum >> 16, OpAdd());
+        const uint64_t s64 = (((uint64_t)r_hi << 16) + r_lo) << 4;      // x^2 = 16 * (|x|/4)^2
+        peak = wave_reduce_dpp(peak, OpMax());
+        bsum = wave_reduce_dpp(bsum, OpAdd());
         if (lane == 0) {
             igdsp_frame_stats st;
             if (l == 0u) {
@@ -246,6 +265,19 @@ __global__ __launch_bounds__(256) void k_meter_wave_per_frame(
             }
             stats[fi] = st;
         }
+    };
+    // One wavefront per channel-frame, eight frames in flight per wave: a single 160-byte load per wave would
+    // leave ~5 KB in flight per CU (0.5 TB/s); the eight loads of consecutive frames are issued back to back
+    // (tail indices clamped so no load is conditional) and then folded one frame at a time.
+    constexpr uint32_t U = 8;
+    const uint32_t last = n_frames - 1u;
+    for (uint32_t f0 = first_frame + (blockIdx.x * 4u + wave) * U; f0 < n_frames; f0 += gridDim.x * 4u * U) {
+        uint32_t w[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) w[u] = load_frame(min(f0 + u, last));
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u)
+            if (f0 + u < n_frames) process_frame(f0 + u, w[u]);     // wave-uniform condition
     }
     if (agg != nullptr) agg_commit_block(agg, rank, agg_slots, 4u, a_sumsq, a_samples, a_frames, a_sil, a_clip, a_bm, a_peak);
 }
@@ -1216,7 +1248,7 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
         if (e != hipSuccess) return e;
     }
     if (done < n_frames) {
-        const uint32_t grid = blocks_for(n_frames - done, 4, (uint32_t)cfg.compute_units * 4u);
+        const uint32_t grid = blocks_for((n_frames - done + 7) / 8, 4, (uint32_t)cfg.compute_units * 8u);
         hipLaunchKernelGGL(k_meter_wave_per_frame, dim3(grid), dim3(256), 0, s, payload, codec, len, C, done, n_frames, n, stats, pcm, agg, rank);
     }
     return hipGetLastError();
