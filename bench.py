@@ -32,7 +32,8 @@ N_SAMPLES = 160
 # algorithmic bytes per sample, meter-only = (160 payload + 1 codec id + 16 result) / 160
 BYTES_PER_SAMPLE = {"meter": (160 + 1 + 16) / 160.0, "store": (160 + 1 + 16 + 320) / 160.0,
                     "roundtrip": (160 + 1 + 16 + 160) / 160.0,   # config #5: read 1 + write 1 + record
-                    "depayload": (180 + 160 + 2 + 8) / 160.0}    # 8(f) rank 1: 180 B packet in, dense payload + len + info out
+                    "depayload": (180 + 160 + 2 + 8) / 160.0,
+                    "rtp": (192 + 1 + 16 + 8) / 160.0}           # fused: 192 B packet slot in, record + info out    # 8(f) rank 1: 180 B packet in, dense payload + len + info out
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -43,7 +44,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels", type=int, default=65536, help="channels PER GPU")
     ap.add_argument("--frames", type=int, default=128)
-    ap.add_argument("--mode", choices=["meter", "store", "roundtrip", "depayload"], default="meter")
+    ap.add_argument("--mode", choices=["meter", "store", "roundtrip", "depayload", "rtp"], default="meter")
     ap.add_argument("--variant", type=int, default=0, help="0 tuned default, 1 wave-per-frame, 2 chunk32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -137,6 +138,15 @@ def main():
         d_radio = torch.ones((C_,), dtype=torch.uint8, device="cuda")
         d_len = torch.empty((F_ * C_,), dtype=torch.int16, device="cuda")
         d_info = torch.empty((F_ * C_,), dtype=torch.int64, device="cuda")
+    d_slots = None
+    if args.mode == "rtp":                                                # [F][C][192] slots: size 180, PT 0, payload at +32
+        d_slots = torch.empty((F_, C_, 192), dtype=torch.uint8, device="cuda")
+        ctx.gen_uniform(d_slots, d_slots.numel(), seed=7, stream=hs)
+        d_slots[:, :, 0] = 180
+        d_slots[:, :, 1:12] = 0
+        d_slots[:, :, 12] = 0x90
+        d_slots[:, :, 13] = 0
+        d_info = torch.empty((F_ * C_,), dtype=torch.int64, device="cuda")
     if args.mode == "roundtrip":                                          # BASELINE configs[4]: mixed A-law / mu-law
         d_cd[1::2] = 8
         d_out = torch.empty_like(d_pl)
@@ -155,7 +165,9 @@ def main():
         aggs[b].zero_()
         if timer is not None:
             timer.start(hs)
-        if args.mode == "depayload":
+        if args.mode == "rtp":
+            ctx.decode_meter_rtp(d_slots, d_cd, C_, F_, d_st, info=d_info, agg=aggs[b], rank=rank, stream=hs)
+        elif args.mode == "depayload":
             ctx.depayload(d_pk, None, d_radio, C_, F_, 180, n, d_pl, d_len, d_info, stream=hs)
         elif args.mode == "roundtrip":
             ctx.roundtrip_peakhold(d_pl, d_cd, C_, F_, n, d_out, d_st, d_hold, stream=hs)
@@ -203,7 +215,7 @@ def main():
     value = total_samples / dt / 1e6
     bps = BYTES_PER_SAMPLE[args.mode]
     achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9
-    kernel_name = "k_depayload16" if args.mode == "depayload" else "k_roundtrip_chunk64" if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64")
+    kernel_name = "k_meter_rtp64" if args.mode == "rtp" else "k_depayload16" if args.mode == "depayload" else "k_roundtrip_chunk64" if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64")
 
     out = {
         "metric": "Msamples/s G.711 decode+RMS, 65536ch@8kHz; %HBM roofline at 1/2/4/8 GPU",

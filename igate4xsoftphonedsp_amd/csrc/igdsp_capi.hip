@@ -415,6 +415,23 @@ int igdsp_depayload(igdsp_ctx *ctx, const uint8_t *d_packets, const uint16_t *d_
     return IGDSP_OK;
 }
 
+int igdsp_decode_meter_rtp(igdsp_ctx *ctx, const uint8_t *d_slots, const uint8_t *d_codec, uint32_t C, uint32_t F,
+                           igdsp_frame_stats *d_stats, igdsp_rtp_info *d_info, igdsp_aggregate *d_agg, uint32_t rank, void *stream)
+{
+    if (!ctx) return IGDSP_EINVAL;
+    if ((uint64_t)C * F == 0) return IGDSP_OK;
+    if (!d_slots || !d_codec || !d_stats || rank >= IGDSP_AGG_MAX_RANKS) return IGDSP_EINVAL;
+    if (int rc = check_shape(C, F, IGDSP_SAMPLES_PER_FRAME)) return rc;
+    // the fused kernel consumes whole 64-slot super-chunks of 16-byte aligned slots; other shapes take the
+    // two-step route (igdsp_depayload + igdsp_decode_meter) — rejected here rather than silently re-routed
+    if (((uint64_t)C * F) % 64u || (reinterpret_cast<uintptr_t>(d_slots) & 15u) || (reinterpret_cast<uintptr_t>(d_stats) & 15u) ||
+        (reinterpret_cast<uintptr_t>(d_info) & 7u))
+        return fail(ctx, IGDSP_EINVAL, "decode_meter_rtp needs C*F % 64 == 0 and 16-byte aligned slots / stats");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_decode_meter_rtp(cfg_of(ctx), d_slots, d_codec, C, F, d_stats, d_info, d_agg, rank, pick(ctx, stream)));
+    return IGDSP_OK;
+}
+
 int igdsp_g726_reorder(igdsp_ctx *ctx, const uint8_t *d_in, uint8_t *d_out, uint64_t n_bytes, int mode, void *stream)
 {
     if (!ctx || mode < 1 || mode > 4) return IGDSP_EINVAL;

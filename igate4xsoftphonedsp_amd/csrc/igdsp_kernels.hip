@@ -666,6 +666,185 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
 }
 
 // ============================================================================
+// Fused packet path — k_meter_rtp64: depayload + decode + meter in one pass over 192-byte packet slots
+// (include/igdsp.h, igdsp_decode_meter_rtp).  Same machinery as k_meter_chunk64 with 12 pieces per
+// slot instead of 10: pieces 0 and 1 of a slot are {size, pad, RTP bytes 0-3} and {RTP bytes 4-19}; they
+// run through the pipeline like payload (wasted LUT work on 1/6 of the pieces) but their strip entries
+// carry header words instead of partial sums, so the slot's frame lane sees PT / size / ED-137 word at
+// fold time and either emits the record or marks the frame EMPTY.  Reads 192 B per frame where the
+// two-kernel pipeline (depayload then meter) moves 180 + 160 + 160 + records.
+// ============================================================================
+constexpr int kSlotPieces = IGDSP_SLOT_BYTES / 16;                 // 12
+constexpr int kRtpHalfLoads = kSlotPieces * kChunkFrames / 64;     // 6 loads per lane per 32-slot half
+constexpr int kRtpStrip = kSuperFrames * kSlotPieces;              // 768 entries = 6 KiB per wave
+constexpr int kRtpWaves = 12;                                      // 64 KiB LUT + 72 KiB strips
+
+__device__ __forceinline__ void rtp_half(const uint2 *lut, uint2 *strip_half, uint4 (&d)[kRtpHalfLoads],
+                                         const uint32_t (&lm)[kRtpHalfLoads], const uint32_t (&pm)[kRtpHalfLoads],
+                                         const uint32_t (&hs)[kRtpHalfLoads], const uint32_t off, const uint32_t lane,
+                                         const uint4 *refill)
+{
+    uint2 e[2][8];
+    uint32_t wa[2], wb[2];
+    auto issue = [&](int u) {
+        const int j = u >> 1, k = u & 1;
+        wa[k] = (u & 1) ? d[j].z : d[j].x;
+        wb[k] = (u & 1) ? d[j].w : d[j].y;
+        const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lm[j], tb = (wb[k] & 0x7F7F7F7Fu) | lm[j];
+        e[k][0] = lut_at(lut, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lut, ta, off, 0x0C0C0500u);
+        e[k][2] = lut_at(lut, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lut, ta, off, 0x0C0C0700u);
+        e[k][4] = lut_at(lut, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lut, tb, off, 0x0C0C0500u);
+        e[k][6] = lut_at(lut, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lut, tb, off, 0x0C0C0700u);
+    };
+    uint32_t sum = 0, peak = 0, bsum = 0;
+    issue(0);
+#pragma unroll
+    for (int u = 0; u < 2 * kRtpHalfLoads; ++u) {
+        const int j = u >> 1, k = u & 1;
+        if (u + 1 < 2 * kRtpHalfLoads) issue(u + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        bsum = __builtin_amdgcn_sad_u8(wa[k], 0u, bsum);
+        bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
+        sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
+        sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
+        peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
+        peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
+        if (k == 1) {
+            uint2 ent = make_uint2(sum, peak | (bsum << 16) | probe_fail(d[j], pm[j]));
+            // header pieces: piece 0 -> {size word, RTP bytes 0-3}; piece 1 -> {ext profile/length, ED-137 word}
+            if (hs[j] == 1u) ent = make_uint2(d[j].x, d[j].w);
+            if (hs[j] == 2u) ent = make_uint2(d[j].z, d[j].w);
+            strip_half[j * 64 + lane] = ent;
+            d[j] = ld_stream(refill + j * 64);
+            sum = 0; peak = 0; bsum = 0;
+        }
+    }
+}
+
+template <bool AGG>
+__global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
+    const uint8_t *__restrict__ slots, const uint8_t *__restrict__ codec, uint32_t C, uint32_t n_frames,
+    igdsp_frame_stats *__restrict__ stats, igdsp_rtp_info *__restrict__ info, igdsp_aggregate *agg, uint32_t rank)
+{
+    __shared__ uint2 lds[kLutEntries + kRtpWaves * kRtpStrip];
+    __shared__ uint32_t next_item;
+    fill_lut(lds);
+    if (threadIdx.x == 0) next_item = kRtpWaves;
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2 *strip = lds + kLutEntries + wave * kRtpStrip;
+    const uint32_t off = (lane & 31u) * 8u;
+    uint32_t fr[kRtpHalfLoads], pm[kRtpHalfLoads], hs[kRtpHalfLoads];
+#pragma unroll
+    for (int j = 0; j < kRtpHalfLoads; ++j) {
+        const uint32_t p = (uint32_t)j * 64u + lane;
+        fr[j] = p / 12u;                                  // slot within the 32-slot half
+        const uint32_t q = p - fr[j] * 12u;               // piece within the slot: 0, 1 header; 2..11 payload
+        hs[j] = q < 2u ? q + 1u : 0u;
+        pm[j] = q < 2u ? 0u : probe_mask(q - 2u);
+    }
+    const uint32_t G = gridDim.x;
+    const uint32_t n_super = n_frames / kSuperFrames;
+    const uint4 *src16 = reinterpret_cast<const uint4 *>(slots);
+    uint64_t a_sumsq = 0;
+    uint32_t a_frames = 0, a_sil = 0, a_clip = 0, a_bm = 0, a_peak = 0;
+
+    auto fetch_half = [&](uint4 (&dst)[kRtpHalfLoads], uint32_t sidx, uint32_t half) {
+        const uint32_t p0 = sidx * (uint32_t)kRtpStrip + half * (uint32_t)(kRtpStrip / 2) + lane;
+#pragma unroll
+        for (int j = 0; j < kRtpHalfLoads; ++j) dst[j] = ld_stream(src16 + (p0 + (uint32_t)j * 64u));
+    };
+    auto fetch_pt = [&](uint32_t sidx) { return (uint32_t)codec[(sidx * (uint32_t)kSuperFrames + lane) % C]; };
+    auto grab = [&]() {
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(&next_item, 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    };
+
+    uint32_t sidx = blockIdx.x + wave * G;
+    if (sidx < n_super) {
+        uint4 X[kRtpHalfLoads], Y[kRtpHalfLoads];
+        uint32_t cur_pt = fetch_pt(sidx);
+        fetch_half(X, sidx, 0);
+        fetch_half(Y, sidx, 1);
+        uint32_t k_next = grab();
+        for (;;) {
+            const uint32_t s_next = blockIdx.x + k_next * G;
+            const bool has_next = s_next < n_super;
+            const uint32_t s_load = has_next ? s_next : 0u;
+            const uint32_t f0 = sidx * kSuperFrames;
+            const bool my_alaw = cur_pt == IGDSP_PT_PCMA;
+            const uint64_t amask = __ballot(my_alaw);
+            const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
+            uint32_t lm0[kRtpHalfLoads], lm1[kRtpHalfLoads];
+#pragma unroll
+            for (int j = 0; j < kRtpHalfLoads; ++j) {
+                lm0[j] = (uint32_t)__builtin_amdgcn_sbfe(am_lo, fr[j], 1) & 0x80808080u;
+                lm1[j] = (uint32_t)__builtin_amdgcn_sbfe(am_hi, fr[j], 1) & 0x80808080u;
+            }
+            const uint4 *nsrc = src16 + (s_load * (uint32_t)kRtpStrip + lane);
+            const uint32_t nxt_pt = fetch_pt(s_load);
+            rtp_half(lds, strip, X, lm0, pm, hs, off, lane, nsrc);
+            rtp_half(lds, strip + kRtpStrip / 2, Y, lm1, pm, hs, off, lane, nsrc + kRtpStrip / 2);
+            if (has_next) k_next = grab();
+            wave_lds_fence();
+            {
+                const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kSlotPieces);   // 96-byte rows
+                const uint4 h = row[0];                   // {size word, RTP bytes 0-3, ext profile/length, ED-137 word}
+                uint64_t s = 0;
+                uint32_t peak = 0, bsum = 0, fail = 0;
+#pragma unroll
+                for (int i = 1; i < kSlotPieces / 2; ++i) {
+                    const uint4 v = row[i];
+                    s += (uint64_t)(v.x + v.z);
+                    peak = max(max(peak, v.y & 0x7FFFu), v.w & 0x7FFFu);
+                    bsum += ((v.y >> 16) & 0x7FFFu) + ((v.w >> 16) & 0x7FFFu);
+                    fail |= v.y | v.w;
+                }
+                // header: same rules as parse_rtp() on a radio call
+                const uint32_t size = h.x & 0xFFFFu, w0 = h.y, pt = (w0 >> 8) & 0x7Fu;
+                uint32_t hf = (((w0 >> 6) & 3u) == 2u ? IGDSP_RTP_V2 : 0u) | ((w0 & 0x10u) ? IGDSP_RTP_X : 0u) |
+                              ((w0 & 0x8000u) ? IGDSP_RTP_MARKER : 0u);
+                uint32_t ed = 0, plen = 0;
+                if (size < 20u) hf = IGDSP_RTP_RUNT;
+                else {
+                    plen = size - 20u;
+                    if (pt == 8u || pt == 0u || pt == 18u || pt == 123u) ed = __builtin_bswap32(h.w);
+                    if ((w0 & 0x10u) && h.z == 0x01006701u) hf |= IGDSP_RTP_ED137_OK;
+                    if (pt == 123u) hf |= IGDSP_RTP_KEEPALIVE;
+                    if (plen > (uint32_t)kFrame) hf |= IGDSP_RTP_OVERSIZE;
+                    else if ((pt == 0u || pt == 8u) && plen > 0u) hf |= IGDSP_RTP_METERED;
+                }
+                const bool metered = size == 180u && pt == cur_pt && (pt == 0u || pt == 8u);
+                const uint32_t fi = f0 + lane;
+                if (info != nullptr) {
+                    uint2 rec;
+                    rec.x = ed;
+                    rec.y = (size < 20u ? 0u : plen) | (((size >= 2u + 12u - 12u) ? pt : 0u) << 16) | (hf << 24);
+                    *reinterpret_cast<uint2 *>(info + fi) = rec;
+                }
+                uint32_t bm = 0, fl = 0;
+                uint4 rec = make_uint4(0u, 0u, 0u, (uint32_t)IGDSP_FLAG_EMPTY << 24);
+                if (metered) rec = pack_stats160(s, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl);
+                st_stream(reinterpret_cast<uint4 *>(stats + fi), rec);
+                if (AGG && metered) {
+                    a_sumsq += s << 4; a_frames += 1u; a_sil += (fl & IGDSP_FLAG_SILENT) ? 1u : 0u;
+                    a_clip += (fl & IGDSP_FLAG_CLIPPED) ? 1u : 0u; a_bm += bm; a_peak = max(a_peak, peak);
+                }
+            }
+            wave_lds_fence();
+            if (!has_next) break;
+            sidx = s_next;
+            cur_pt = nxt_pt;
+        }
+    }
+    if (AGG && agg != nullptr)
+        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kRtpWaves, a_sumsq, (uint64_t)a_frames * kFrame, a_frames,
+                         a_sil, a_clip, a_bm, a_peak);
+}
+
+// ============================================================================
 // a2 — G.711 compression.  ONE branch-free formulation serves both laws and both encoder lineages
 // (include/igdsp.h): per-law constants select bias / rounding, the segment comes from count-leading-
 // zeros.  With msb = 31 - clz(mag):
@@ -1251,6 +1430,18 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
         const uint32_t grid = blocks_for((n_frames - done + 7) / 8, 4, (uint32_t)cfg.compute_units * 8u);
         hipLaunchKernelGGL(k_meter_wave_per_frame, dim3(grid), dim3(256), 0, s, payload, codec, len, C, done, n_frames, n, stats, pcm, agg, rank);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_meter_rtp(const LaunchCfg &cfg, const uint8_t *slots, const uint8_t *codec, uint32_t C, uint32_t F,
+                                   igdsp_frame_stats *stats, igdsp_rtp_info *info, igdsp_aggregate *agg, uint32_t rank,
+                                   hipStream_t s)
+{
+    const uint32_t n_frames = C * F;                       // caller guarantees a multiple of 64
+    if (n_frames == 0) return hipSuccess;
+    const uint32_t grid = blocks_for(n_frames / kSuperFrames, kRtpWaves, (uint32_t)cfg.compute_units);
+    if (agg) hipLaunchKernelGGL((k_meter_rtp64<true>), dim3(grid), dim3(kRtpWaves * 64), 0, s, slots, codec, C, n_frames, stats, info, agg, rank);
+    else     hipLaunchKernelGGL((k_meter_rtp64<false>), dim3(grid), dim3(kRtpWaves * 64), 0, s, slots, codec, C, n_frames, stats, info, agg, rank);
     return hipGetLastError();
 }
 

@@ -263,6 +263,23 @@ int igdsp_depayload(igdsp_ctx *ctx, const uint8_t *d_packets, const uint16_t *d_
                     uint32_t n_channels, uint32_t n_frames, uint32_t pkt_stride, uint32_t samples_per_frame,
                     uint8_t *d_payload_out, uint16_t *d_len_out, igdsp_rtp_info *d_info_out, void *stream);
 
+/* ---- Fused fast path: packet slots straight into the meter (depayload + decode + meter in ONE kernel) ----
+ * For receivers that deposit radio-call packets (20-byte ED-137 header + 160-byte G.711 payload = 180 bytes,
+ * TransportAdapter.cpp:846) into fixed 192-byte slots laid out so the payload is 16-byte aligned:
+ *     bytes 0..1   received packet size (uint16 LE)         bytes 2..11  reserved (0)
+ *     bytes 12..31 the 20-byte header (custom_rtp_hdr)      bytes 32..191 payload
+ * slots[f][c][192].  A frame is metered iff size == 180 and its RTP PT equals codec[c] (0 or 8); every
+ * other slot (PT 123 keep-alive, other PT, other size) gets an IGDSP_FLAG_EMPTY record — route those
+ * rare frames through igdsp_depayload + igdsp_decode_meter(d_len) if they must be metered.
+ * d_info (optional) receives the same igdsp_rtp_info igdsp_depayload would produce. */
+#define IGDSP_SLOT_BYTES      192
+#define IGDSP_SLOT_HDR_OFFSET  12
+#define IGDSP_SLOT_PAYLOAD_OFFSET 32
+int igdsp_decode_meter_rtp(igdsp_ctx *ctx, const uint8_t *d_slots, const uint8_t *d_codec,
+                           uint32_t n_channels, uint32_t n_frames,
+                           igdsp_frame_stats *d_stats, igdsp_rtp_info *d_info,
+                           igdsp_aggregate *d_agg, uint32_t rank, void *stream);
+
 /* ---- G.726 code-word reorder (RoIP_ED137::changeUplinkOrder, roip_ed137.cpp:6379-6499) ----
  * Repacks G.726 code words between the RFC 3551 and AAL2 bit orders, bug-for-bug as the reference
  * does it on its (unsigned-char) target:

@@ -137,3 +137,59 @@ def test_depayload_agrees_with_host_transport_rtp_cb(ctx, orc):
     assert checked > 10
     for a in adapters:
         L.igdsp_host_adapter_free(a)
+
+
+def _to_slots(pk180, sizes):
+    """[F][C][180] packets + sizes -> [F][C][192] slots: u16 size, 10 reserved bytes, packet at +12."""
+    F_, C_, _ = pk180.shape
+    slots = np.zeros((F_, C_, 192), np.uint8)
+    slots[:, :, 0] = sizes & 0xFF
+    slots[:, :, 1] = sizes >> 8
+    slots[:, :, 12:] = pk180
+    return slots
+
+
+@pytest.mark.parametrize("C_,F_", [(64, 3), (96, 2), (256, 5), (32, 2)])
+def test_fused_rtp_slots_meter(ctx, orc, C_, F_):
+    """igdsp_decode_meter_rtp: one kernel from packet slots to records.  info == the depayload oracle;
+    metered frames (size 180, PT == codec) == the meter oracle; everything else EMPTY; aggregate over metered only."""
+    torch = gu.torch_cuda()
+    n = 160
+    pk, sizes, _ = _make_packets(orc, C_, F_, 180, n, seed=C_ * 10 + F_)
+    radio = np.ones((C_,), np.uint8)
+    # re-make as all-radio packets with mostly full audio frames
+    rng = np.random.default_rng(C_ + F_)
+    codec = np.where(np.arange(C_) % 3 == 0, 8, 0).astype(np.uint8)
+    for f in range(F_):
+        for c in range(C_):
+            kind = rng.integers(0, 10)
+            pt = int(codec[c]) if kind < 6 else [123, 18, 8 - int(codec[c]), 96][kind - 6]
+            plen = n if kind != 9 else 24
+            if kind == 6:
+                plen = 0
+            body = orc.gen_uniform(max(plen, 1), seed=f * 1000 + c).tobytes()[:plen]
+            pkt = hu.rtp_packet(pt, f, body, True, int(rng.integers(0, 2 ** 32)))
+            pk[f, c, :] = orc.gen_uniform(180, seed=7).astype(np.uint8)       # stale bytes behind short packets
+            pk[f, c, :len(pkt)] = np.frombuffer(pkt, np.uint8)
+            sizes[f, c] = len(pkt) if kind != 8 or f % 2 else int(rng.integers(0, 20))   # some runts
+    slots = _to_slots(pk, sizes)
+    d_st, d_info, d_agg = gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.dev_zeros(F_ * C_ * 8, 0xEE), gu.dev_zeros(capi.AGGREGATE.itemsize)
+    ctx.decode_meter_rtp(gu.to_dev(slots), gu.to_dev(codec), C_, F_, d_st, info=d_info, agg=d_agg, rank=2)
+    torch.cuda.synchronize()
+    epl, elen, einfo = orc.depayload(pk, sizes, radio, n)
+    ginfo = gu.to_host(d_info, capi.RTP_INFO, (F_, C_))
+    for fld in capi.RTP_INFO.names:
+        assert np.array_equal(ginfo[fld], einfo[fld]), fld
+    metered = (sizes == 180) & (einfo["pt"] == codec[None, :]) & np.isin(einfo["pt"], (0, 8))
+    assert metered.any() and (~metered).any()
+    est = orc.decode_meter(epl, codec)
+    gst = gu.to_host(d_st, capi.FRAME_STATS, (F_, C_))
+    gu.assert_stats_equal(gst[metered].reshape(1, -1), est[metered].reshape(1, -1), n=n)
+    emp = gst[~metered]
+    assert np.all(emp["flags"] == capi.FLAG_EMPTY) and np.all(emp["sumsq"] == 0) and np.all(emp["peak"] == 0) and np.all(emp["rms"] == 0)
+    agg = gu.to_host(d_agg, capi.AGGREGATE)[0]
+    assert int(agg["frames"]) == int(metered.sum()) and int(agg["samples"]) == int(metered.sum()) * n
+    assert int(agg["sumsq"]) == int(est["sumsq"][metered].sum(dtype=np.uint64))
+    assert int(agg["peak_slot"][2]) == int(est["peak"][metered].max())
+    # shape / alignment rules are reported, not silently re-routed
+    assert ctx.L.igdsp_decode_meter_rtp(ctx.h, d_st.data_ptr(), d_st.data_ptr(), 33, 1, d_st.data_ptr(), None, None, 0, None) == -22
