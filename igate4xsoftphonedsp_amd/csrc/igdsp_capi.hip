@@ -460,6 +460,16 @@ int igdsp_stream_read(igdsp_ctx *ctx, const void *d_src, size_t bytes, uint64_t 
     return IGDSP_OK;
 }
 
+// Test-only (not in include/igdsp.h): the table-driven compressor the fused round-trip kernel uses, on arbitrary PCM.
+int igdsp_internal_encode_table(igdsp_ctx *ctx, const int16_t *d_pcm, const uint8_t *d_codec, uint32_t C, uint32_t F, uint32_t n,
+                                uint8_t *d_out, int variant, void *stream)
+{
+    if (!ctx || !d_pcm || !d_codec || !d_out || (variant != IGDSP_ENC_SUN16 && variant != IGDSP_ENC_G191)) return IGDSP_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_encode_table(cfg_of(ctx), d_pcm, d_codec, C, F, n, d_out, variant, pick(ctx, stream)));
+    return IGDSP_OK;
+}
+
 // Diagnostic-only (not in include/igdsp.h): cycle stamps of the chunk32 kernel, 8 x u64 per wavefront
 // {t_begin, t_lut_ready, t_end, sum load-wait, sum process, iterations, sum frame-reduce, xcc id}.
 int igdsp_internal_diag_chunk32(igdsp_ctx *ctx, const uint8_t *d_payload, const uint8_t *d_codec, uint32_t C, uint32_t F,

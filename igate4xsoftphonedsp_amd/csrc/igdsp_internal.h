@@ -36,6 +36,8 @@ hipError_t launch_diag_chunk32(const LaunchCfg &cfg, const uint8_t *payload, con
                                igdsp_frame_stats *stats, uint64_t *diag, hipStream_t s);
 hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t *codec,
                          uint32_t C, uint32_t F, uint32_t n, uint8_t *out, int variant, hipStream_t s);
+hipError_t launch_encode_table(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t *codec, uint32_t C, uint32_t F, uint32_t n,
+                               uint8_t *out, int variant, hipStream_t s);
 hipError_t launch_roundtrip(const LaunchCfg &cfg, const uint8_t *payload, const uint8_t *codec,
                             uint32_t C, uint32_t F, uint32_t n, uint8_t *out, igdsp_frame_stats *stats,
                             igdsp_chan_hold *hold, const uint8_t *gate, int variant, hipStream_t s);

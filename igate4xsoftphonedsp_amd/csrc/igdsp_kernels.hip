@@ -11,6 +11,7 @@
 //   hold / window aggregate       : Functions.cpp:2126-2145, 2155-2167.
 #include "igdsp_internal.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace igdsp {
@@ -894,6 +895,61 @@ __device__ __forceinline__ uint32_t enc_uni(int v, const EncK k)
     return ((sg << 4) | step) ^ k.base ^ ((uint32_t)sign & 0x80u);
 }
 
+// ----------------------------------------------------------------------------
+// Table-driven form of the same compressor (what production G.711 encoders do): 2 laws x 16 384 cells of
+// one byte in LDS, a cell = four neighbouring PCM values on which the compressor is constant:
+//   SUN16 works on sign / magnitude      -> cell = (v < 0, |v| >> 2)         (|v| >> 2 clamped to 8191)
+//   G191  works on the floored 14-bit value -> cell = (v >> 2) + 8192
+// The table is generated at kernel start by running enc_uni on one representative value per cell.
+// ----------------------------------------------------------------------------
+constexpr int kEncCells = 16384;
+
+template <int VARIANT>
+__device__ __forceinline__ uint32_t enc_cell(int v)
+{
+    if (VARIANT == IGDSP_ENC_SUN16) {
+        const int sign = v >> 31;
+        const int av = (v ^ sign) - sign;
+        return ((uint32_t)sign & 8192u) + min((uint32_t)av >> 2, 8191u);
+    }
+    return (uint32_t)((v >> 2) + 8192);
+}
+
+template <int VARIANT>
+__device__ __forceinline__ int enc_cell_value(uint32_t cell)
+{
+    if (VARIANT == IGDSP_ENC_SUN16) {
+        const int k = (int)(cell & 8191u);
+        return (cell & 8192u) ? -(4 * k + 1) : 4 * k;          // (neg, k = 0) is {-1,-2,-3}: zero is never negative
+    }
+    return ((int)cell - 8192) * 4;
+}
+
+template <int VARIANT>
+__device__ __forceinline__ void fill_enc_table(uint8_t *tab)     // tab[2][kEncCells]: mu-law, A-law
+{
+    const EncK ku = enc_consts<VARIANT>(false), ka = enc_consts<VARIANT>(true);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kEncCells; i += blockDim.x) {
+        const int v = enc_cell_value<VARIANT>(i);
+        tab[i] = (uint8_t)enc_uni<VARIANT>(v, ku);
+        tab[kEncCells + i] = (uint8_t)enc_uni<VARIANT>(v, ka);
+    }
+}
+
+// Diagnostic/test entry: the table-driven compressor on arbitrary PCM (exhaustive parity test of the cells).
+template <int VARIANT>
+__global__ __launch_bounds__(1024) void k_encode_table(const int16_t *__restrict__ pcm, const uint8_t *__restrict__ codec,
+                                                       uint32_t C, uint32_t n, uint64_t n_samples, uint8_t *__restrict__ out)
+{
+    __shared__ uint8_t tab[2 * kEncCells];
+    fill_enc_table<VARIANT>(tab);
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = (uint32_t)((i / n) % C);
+        out[i] = tab[(codec[c] == IGDSP_PT_PCMA ? kEncCells : 0) + enc_cell<VARIANT>((int)pcm[i])];
+    }
+}
+
 // 8 samples (16 B) per lane in, 8 codes (8 B) out; requires n % 8 == 0 and 16 B aligned pcm.
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_encode_v8(const int16_t *__restrict__ pcm, const uint8_t *__restrict__ codec,
@@ -938,15 +994,15 @@ __global__ __launch_bounds__(256) void k_encode_scalar(const int16_t *__restrict
 // arithmetic (enc_uni) applied to the decoded PCM value, not a shortcut.  Needs C % 64 == 0, n == 160.
 // ============================================================================
 #ifndef IGDSP_RT_WAVES
-#define IGDSP_RT_WAVES 8
+#define IGDSP_RT_WAVES 12
 #endif
-constexpr int kRtWaves = IGDSP_RT_WAVES;   // 512 threads: the encoder's temporaries need well over 128 VGPRs
+constexpr int kRtWaves = IGDSP_RT_WAVES;   // 64 KiB LUT + 32 KiB compressor table + 12 x 5 KiB strips = 156 KiB
 
 template <int VARIANT>
 __device__ __forceinline__ void roundtrip_half(const uint2 *lut, uint2 *strip_half, uint4 (&d)[kLoadsPerChunk],
                                                const uint32_t (&lm)[kLoadsPerChunk], const uint32_t (&pm)[kLoadsPerChunk],
                                                const uint32_t off, const uint32_t lane, uint4 *out_half, const uint4 *refill,
-                                               const bool do_refill)
+                                               const bool do_refill, const uint8_t *enc_tab)
 {
     uint2 e[2][8];
     uint32_t wa[2], wb[2];
@@ -960,11 +1016,13 @@ __device__ __forceinline__ void roundtrip_half(const uint2 *lut, uint2 *strip_ha
         e[k][4] = lut_at(lut, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lut, tb, off, 0x0C0C0500u);
         e[k][6] = lut_at(lut, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lut, tb, off, 0x0C0C0700u);
     };
-    auto recode4 = [&](uint32_t w, const uint2 &e0, const uint2 &e1, const uint2 &e2, const uint2 &e3, const EncK k) {
-        // decoded PCM value of each code (sign bit set = positive), then the compressor on that value
+    auto recode4 = [&](uint32_t w, const uint2 &e0, const uint2 &e1, const uint2 &e2, const uint2 &e3, const uint8_t *tab) {
+        // decoded PCM value of each code (sign bit set = positive), then the compressor on that value:
+        // the table-driven form of enc_uni (cell lookup in LDS), valid for ANY int16, not only decoder outputs
         const int x0 = (w & 0x80u) ? (int)e0.y : -(int)e0.y, x1 = (w & 0x8000u) ? (int)e1.y : -(int)e1.y;
         const int x2 = (w & 0x800000u) ? (int)e2.y : -(int)e2.y, x3 = (w & 0x80000000u) ? (int)e3.y : -(int)e3.y;
-        return enc_uni<VARIANT>(x0, k) | (enc_uni<VARIANT>(x1, k) << 8) | (enc_uni<VARIANT>(x2, k) << 16) | (enc_uni<VARIANT>(x3, k) << 24);
+        return (uint32_t)tab[enc_cell<VARIANT>(x0)] | ((uint32_t)tab[enc_cell<VARIANT>(x1)] << 8) |
+               ((uint32_t)tab[enc_cell<VARIANT>(x2)] << 16) | ((uint32_t)tab[enc_cell<VARIANT>(x3)] << 24);
     };
     uint32_t sum = 0, peak = 0, bsum = 0;
     uint32_t o[4];
@@ -974,7 +1032,7 @@ __device__ __forceinline__ void roundtrip_half(const uint2 *lut, uint2 *strip_ha
         const int j = u >> 1, k = u & 1;
         if (u + 1 < 2 * kLoadsPerChunk) issue(u + 1);
         __builtin_amdgcn_sched_barrier(0);
-        const EncK ek = enc_consts<VARIANT>(lm[j] != 0u);
+        const uint8_t *ek = enc_tab + (lm[j] != 0u ? kEncCells : 0);
         bsum = __builtin_amdgcn_sad_u8(wa[k], 0u, bsum);
         bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
         sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
@@ -996,10 +1054,17 @@ template <int VARIANT>
 __global__ __launch_bounds__(kRtWaves * 64) void k_roundtrip_chunk64(
     const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F,
     uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats, igdsp_chan_hold *__restrict__ hold,
-    const uint8_t *__restrict__ gate)
+    const uint8_t *__restrict__ gate, uint32_t n_seg)
 {
+    // Work item = (channel group of 64, frame segment): with 65 536 channels there are only 1 024 groups, so the
+    // launcher splits the F frames into n_seg segments to fill the chip.  n_seg == 1: the wave owns its channels'
+    // hold records outright (plain read-modify-write).  n_seg > 1: each item folds its own window and MERGES it into
+    // hold[c] with device-scope integer atomics (adds, and a CAS loop on the {peak_hold, max, min} word) —
+    // exact and order-independent, so the result is bit-identical to the sequential fold.
     __shared__ uint2 lds[kLutEntries + kRtWaves * kStripEntries];
+    __shared__ uint8_t enc_tab[2 * kEncCells];
     fill_lut(lds);
+    fill_enc_table<VARIANT>(enc_tab);
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1016,11 +1081,16 @@ __global__ __launch_bounds__(kRtWaves * 64) void k_roundtrip_chunk64(
     const uint32_t n_groups = C / kSuperFrames;
     const uint32_t fstride16 = C * (uint32_t)kPiecesPerFrame;       // uint4 units between frames of one channel group
 
-    for (uint32_t cg = wave * gridDim.x + blockIdx.x; cg < n_groups; cg += total_waves) {
+    for (uint32_t item = wave * gridDim.x + blockIdx.x; item < n_groups * n_seg; item += total_waves) {
+        const uint32_t seg = item / n_groups, cg = item - seg * n_groups;
+        const uint32_t f_lo = (uint32_t)(((uint64_t)F * seg) / n_seg), f_hi = (uint32_t)(((uint64_t)F * (seg + 1u)) / n_seg);
+        if (f_lo >= f_hi) continue;
         const uint32_t c0 = cg * kSuperFrames, cme = c0 + lane;
         const bool my_alaw = codec[cme] == IGDSP_PT_PCMA;
         const bool open = (gate == nullptr) || (gate[cme] != 0);
-        igdsp_chan_hold h = hold[cme];
+        igdsp_chan_hold h;
+        if (n_seg == 1u) h = hold[cme];
+        else { h.sumsq_acc = 0; h.count = 0; h.level_sum = 0; h.samples = 0; h.peak_hold = 0; h.level_max = 0; h.level_min = 255; h.n_silent = 0; h.n_clipped = 0; }
         const uint64_t amask = __ballot(my_alaw);
         const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
         uint32_t lm0[kLoadsPerChunk], lm1[kLoadsPerChunk];
@@ -1034,16 +1104,16 @@ __global__ __launch_bounds__(kRtWaves * 64) void k_roundtrip_chunk64(
 
         uint4 X[kLoadsPerChunk], Y[kLoadsPerChunk];
 #pragma unroll
-        for (int j = 0; j < kLoadsPerChunk; ++j) X[j] = ld_stream(src + j * 64);
+        for (int j = 0; j < kLoadsPerChunk; ++j) X[j] = ld_stream(src + (uint64_t)f_lo * fstride16 + j * 64);
 #pragma unroll
-        for (int j = 0; j < kLoadsPerChunk; ++j) Y[j] = ld_stream(src + kPiecesPerChunk + j * 64);
+        for (int j = 0; j < kLoadsPerChunk; ++j) Y[j] = ld_stream(src + (uint64_t)f_lo * fstride16 + kPiecesPerChunk + j * 64);
 
-        for (uint32_t f = 0; f < F; ++f) {
-            const bool more = f + 1u < F;                       // wave-uniform; the last frame simply skips its refill
+        for (uint32_t f = f_lo; f < f_hi; ++f) {
+            const bool more = f + 1u < f_hi;                    // wave-uniform; the last frame re-reads itself (cache hit)
             const uint4 *nsrc = src + (uint64_t)(more ? f + 1u : f) * fstride16;
             uint4 *o16 = dst + (uint64_t)f * fstride16;
-            roundtrip_half<VARIANT>(lds, strip, X, lm0, pm, off, lane, o16, nsrc, true);
-            roundtrip_half<VARIANT>(lds, strip + kPiecesPerChunk, Y, lm1, pm, off, lane, o16 + kPiecesPerChunk, nsrc + kPiecesPerChunk, true);
+            roundtrip_half<VARIANT>(lds, strip, X, lm0, pm, off, lane, o16, nsrc, true, enc_tab);
+            roundtrip_half<VARIANT>(lds, strip + kPiecesPerChunk, Y, lm1, pm, off, lane, o16 + kPiecesPerChunk, nsrc + kPiecesPerChunk, true, enc_tab);
             wave_lds_fence();
             {
                 const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kPiecesPerFrame);
@@ -1070,7 +1140,25 @@ __global__ __launch_bounds__(kRtWaves * 64) void k_roundtrip_chunk64(
             }
             wave_lds_fence();
         }
-        hold[cme] = h;
+        if (n_seg == 1u) hold[cme] = h;
+        else if (h.count != 0u) {
+            igdsp_chan_hold *g = hold + cme;
+            atomicAdd((unsigned long long *)&g->sumsq_acc, (unsigned long long)h.sumsq_acc);
+            atomicAdd(&g->count, h.count); atomicAdd(&g->level_sum, h.level_sum); atomicAdd(&g->samples, h.samples);
+            atomicAdd(&g->n_silent, h.n_silent); atomicAdd(&g->n_clipped, h.n_clipped);
+            // {u16 peak_hold, u8 level_max, u8 level_min} share one 32-bit word: merge with a CAS loop
+            uint32_t *pw = reinterpret_cast<uint32_t *>(&g->peak_hold);
+            uint32_t old = *pw, want;
+            do {
+                const uint32_t pk = max(old & 0xFFFFu, (uint32_t)h.peak_hold), mx = max((old >> 16) & 0xFFu, (uint32_t)h.level_max);
+                const uint32_t mn = min(old >> 24, (uint32_t)h.level_min);
+                want = pk | (mx << 16) | (mn << 24);
+                if (want == old) break;
+                const uint32_t seen = atomicCAS(pw, old, want);
+                if (seen == old) break;
+                old = seen;
+            } while (true);
+        }
     }
 }
 
@@ -1477,14 +1565,30 @@ hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t
     return hipGetLastError();
 }
 
+hipError_t launch_encode_table(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t *codec, uint32_t C, uint32_t F, uint32_t n,
+                               uint8_t *out, int variant, hipStream_t s)
+{
+    const uint64_t n_samples = (uint64_t)C * F * n;
+    if (n_samples == 0) return hipSuccess;
+    const uint32_t grid = blocks_for(n_samples, 1024 * 16, (uint32_t)cfg.compute_units);
+    if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_table<IGDSP_ENC_G191>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, n_samples, out);
+    else                           hipLaunchKernelGGL((k_encode_table<IGDSP_ENC_SUN16>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, n_samples, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_roundtrip(const LaunchCfg &cfg, const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F,
                             uint32_t n, uint8_t *out, igdsp_frame_stats *stats, igdsp_chan_hold *hold,
                             const uint8_t *gate, int variant, hipStream_t s)
 {
     if ((uint64_t)C * F == 0) return hipSuccess;
-    const uint32_t grid = blocks_for(C / kSuperFrames, kRtWaves, (uint32_t)cfg.compute_units);
-    if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_G191>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate);
-    else                           hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_SUN16>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate);
+    // fill the chip: at least kRtWaves work items per CU; a segment is never shorter than 8 frames
+    const uint32_t n_groups = C / kSuperFrames;
+    const uint32_t want = (uint32_t)cfg.compute_units * kRtWaves;
+    uint32_t n_seg = n_groups >= want ? 1u : (want + n_groups - 1u) / n_groups;
+    n_seg = std::max(1u, std::min(n_seg, std::max(1u, F / 8u)));
+    const uint32_t grid = blocks_for((uint64_t)n_groups * n_seg, kRtWaves, (uint32_t)cfg.compute_units);
+    if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_G191>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg);
+    else                           hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_SUN16>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg);
     (void)n;
     return hipGetLastError();
 }
