@@ -33,7 +33,8 @@ N_SAMPLES = 160
 BYTES_PER_SAMPLE = {"meter": (160 + 1 + 16) / 160.0, "store": (160 + 1 + 16 + 320) / 160.0,
                     "roundtrip": (160 + 1 + 16 + 160) / 160.0,   # config #5: read 1 + write 1 + record
                     "depayload": (180 + 160 + 2 + 8) / 160.0,
-                    "rtp": (192 + 1 + 16 + 8) / 160.0}           # fused: 192 B packet slot in, record + info out    # 8(f) rank 1: 180 B packet in, dense payload + len + info out
+                    "rtp": (192 + 1 + 16 + 8) / 160.0,           # fused: 192 B packet slot in, record + info out
+                    "encode": (320 + 1 + 160) / 160.0}           # a2: int16 in, code out    # 8(f) rank 1: 180 B packet in, dense payload + len + info out
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -44,7 +45,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels", type=int, default=65536, help="channels PER GPU")
     ap.add_argument("--frames", type=int, default=128)
-    ap.add_argument("--mode", choices=["meter", "store", "roundtrip", "depayload", "rtp"], default="meter")
+    ap.add_argument("--mode", choices=["meter", "store", "roundtrip", "depayload", "rtp", "encode"], default="meter")
     ap.add_argument("--variant", type=int, default=0, help="0 tuned default, 1 wave-per-frame, 2 chunk32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -138,6 +139,11 @@ def main():
         d_radio = torch.ones((C_,), dtype=torch.uint8, device="cuda")
         d_len = torch.empty((F_ * C_,), dtype=torch.int16, device="cuda")
         d_info = torch.empty((F_ * C_,), dtype=torch.int64, device="cuda")
+    d_pcm_in = None
+    if args.mode == "encode":
+        d_pcm_in = torch.empty((F_, C_, n), dtype=torch.int16, device="cuda")
+        ctx.gen_uniform(d_pcm_in, d_pcm_in.numel() * 2, seed=11, stream=hs)
+        d_out = torch.empty_like(d_pl)
     d_slots = None
     if args.mode == "rtp":                                                # [F][C][192] slots: size 180, PT 0, payload at +32
         d_slots = torch.empty((F_, C_, 192), dtype=torch.uint8, device="cuda")
@@ -165,7 +171,9 @@ def main():
         aggs[b].zero_()
         if timer is not None:
             timer.start(hs)
-        if args.mode == "rtp":
+        if args.mode == "encode":
+            ctx.encode(d_pcm_in, d_cd, C_, F_, n, d_out, stream=hs)
+        elif args.mode == "rtp":
             ctx.decode_meter_rtp(d_slots, d_cd, C_, F_, d_st, info=d_info, agg=aggs[b], rank=rank, stream=hs)
         elif args.mode == "depayload":
             ctx.depayload(d_pk, None, d_radio, C_, F_, 180, n, d_pl, d_len, d_info, stream=hs)
@@ -215,7 +223,7 @@ def main():
     value = total_samples / dt / 1e6
     bps = BYTES_PER_SAMPLE[args.mode]
     achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9
-    kernel_name = "k_meter_rtp64" if args.mode == "rtp" else "k_depayload16" if args.mode == "depayload" else "k_roundtrip_chunk64" if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64")
+    kernel_name = "k_encode_v8" if args.mode == "encode" else "k_meter_rtp64" if args.mode == "rtp" else "k_depayload16" if args.mode == "depayload" else "k_roundtrip_chunk64" if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64")
 
     out = {
         "metric": "Msamples/s G.711 decode+RMS, 65536ch@8kHz; %HBM roofline at 1/2/4/8 GPU",

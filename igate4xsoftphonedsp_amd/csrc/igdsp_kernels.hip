@@ -284,12 +284,7 @@ __global__ __launch_bounds__(256) void k_meter_wave_per_frame(
 }
 
 // ============================================================================
-// Variant 2 (default for n == 160) — "chunk32": one wavefront owns 32
-// consecutive channel-frames = 5120 contiguous bytes, fetched as five wave-wide
-// 16 B/lane loads (1 KiB per instruction, fully coalesced).  A 16-byte piece
-// never straddles a frame (160 = 10 x 16), so each lane reduces its piece
-// privately; the 10 pieces of a frame are then folded by one "frame lane"
-// through a per-wave LDS strip.
+// Shared machinery of the tuned n == 160 kernels (k_meter_chunk64, k_meter_rtp64, k_roundtrip_chunk64).
 //
 // Expansion LUT: 256 entries (law<<7 | code&0x7F) x 32 replicas x 8 B = 64 KiB
 // in LDS, entry = { (|x|/4)^2 , |x| }.  Replica r sits at byte offset r*8 of the
@@ -323,35 +318,6 @@ __device__ __forceinline__ uint32_t pack_pcm(uint32_t w, uint32_t k, uint32_t ax
     const int x0 = (w & (0x80u << (8u * k))) ? (int)ax0 : -(int)ax0;
     const int x1 = (w & (0x8000u << (8u * k))) ? (int)ax1 : -(int)ax1;
     return ((uint32_t)x0 & 0xFFFFu) | ((uint32_t)x1 << 16);
-}
-
-template <bool STORE_PCM>
-__device__ __forceinline__ void piece16(const uint2 *lut, const uint4 d, const uint32_t lawmask, const uint32_t off,
-                                        uint32_t &sum, uint32_t &peak, uint32_t &bsum, uint4 &o0, uint4 &o1)
-{
-    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
-    uint32_t o[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        bsum = __builtin_amdgcn_sad_u8(w[i], 0u, bsum);
-        const uint32_t t = (w[i] & 0x7F7F7F7Fu) | lawmask;
-        const uint2 e0 = lut_at(lut, t, off, 0x0C0C0400u);
-        const uint2 e1 = lut_at(lut, t, off, 0x0C0C0500u);
-        const uint2 e2 = lut_at(lut, t, off, 0x0C0C0600u);
-        const uint2 e3 = lut_at(lut, t, off, 0x0C0C0700u);
-        sum = sum + e0.x + e1.x;
-        sum = sum + e2.x + e3.x;
-        peak = max(max(peak, e0.y), e1.y);
-        peak = max(max(peak, e2.y), e3.y);
-        if (STORE_PCM) {
-            o[2 * i] = pack_pcm(w[i], 0, e0.y, e1.y);
-            o[2 * i + 1] = pack_pcm(w[i], 2, e2.y, e3.y);
-        }
-    }
-    if (STORE_PCM) {
-        o0 = make_uint4(o[0], o[1], o[2], o[3]);
-        o1 = make_uint4(o[4], o[5], o[6], o[7]);
-    }
 }
 
 __device__ __forceinline__ void wave_lds_fence()

@@ -18,8 +18,8 @@ KEY = "k_meter_chunk64"
 
 
 def one(pattern):
-    g = glob.glob(os.path.join(src, pattern), recursive=True)
-    return g[0] if g else None
+    g = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
+    return g[-1] if g else None      # newest: gpurun merges into an existing directory
 
 
 lines = [f"# rocprofv3 summary — {tag} — `python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline` (1x MI355X)", ""]
