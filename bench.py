@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on GPUs; gloo only to rehearse the N>1 path on one GPU")
     ap.add_argument("--one-gpu-rehearsal", action="store_true", help="all ranks use cuda:0 (with --backend gloo)")
     ap.add_argument("--no-agg", action="store_true", help="experiment: skip the launch aggregate (N=1 only)")
-    ap.add_argument("--stream-calib", action="store_true", help="also time the read-only stream kernel")
+    ap.add_argument("--no-stream-calib", action="store_true", help="skip the read-only stream calibration kernel")
     return ap.parse_args()
 
 
@@ -255,7 +255,7 @@ def main():
         "aggregate": {"node_rms": round(node["rms"], 3), "node_peak": node["peak"], "samples": node["samples"]},
     }
 
-    if args.stream_calib:
+    if not args.no_stream_calib:
         sink = torch.zeros((1,), dtype=torch.int64, device="cuda")
         tm = ctx.timer()
         for _ in range(3):

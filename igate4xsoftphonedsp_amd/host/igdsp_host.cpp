@@ -220,9 +220,10 @@ void transport_rtp_cb(void *user_data, void *pkt, long size)
         adapter->payloadsize = rtphdr->length;
     }
     long payloadlen = size - hdr;
-    if (payloadlen < 0) payloadlen = 0;
-    // the reference guards with `< 1024` into a 256-byte buffer (TransportAdapter.cpp:286); we clamp to the buffer
-    if (payloadlen > (long)sizeof(adapter->payload_buff)) {
+    // runt (shorter than its header): the reference's unsigned subtraction wraps, fails its `< 1024` guard and
+    // returns (TransportAdapter.cpp:279-291); oversize: it guards with `< 1024` into a 256-byte buffer (:286) —
+    // both are dropped here without touching the buffers
+    if (payloadlen < 0 || payloadlen > (long)sizeof(adapter->payload_buff)) {
         adapter->r2sPacket = now_ms();
         return;
     }

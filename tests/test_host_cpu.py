@@ -47,3 +47,49 @@ def test_host_create_fails_loudly_without_gpu():
     L = hu.load()
     assert not L.igdsp_host_create(0, 4)          # NULL: no device, no CPU metering path
     assert L.igdsp_host_tick(None, None) == -22
+
+
+def test_transport_rtp_cb_fuzz_against_depayload_oracle(orc):
+    """CPU only: the host mirror's transport_rtp_cb (header parse, PT gate, payload copy, keep-alive / oversize
+    handling) against the oracle's restatement of TransportAdapter.cpp:240-292 on random packets.  No RoIP_ED137
+    instance exists here, so nothing is metered — this exercises the parsing and the 256-byte buffer guard."""
+    import socket
+
+    L = hu.load()
+    rng = np.random.default_rng(11)
+    adapters = {0: L.igdsp_host_adapter_new(1, 0), 1: L.igdsp_host_adapter_new(2, 1)}
+    for it in range(400):
+        radio = int(rng.integers(0, 2))
+        hdr = 20 if radio else 12
+        pt = int(rng.choice([0, 8, 18, 123, 96, 3]))
+        plen = int(rng.choice([160, 160, 24, 164, 0, 255, 256, 257, 300, 1]))
+        size = hdr + plen
+        pkt = bytearray(hu.rtp_packet(pt, it, rng.integers(0, 256, plen, dtype=np.uint8).tobytes(), bool(radio), int(rng.integers(0, 2 ** 32))))
+        if it % 9 == 0:
+            size = int(rng.integers(0, hdr))                     # runt
+        a = adapters[radio].contents
+        before = (a.payload_bufSize, bytes(a.payload_buff))
+        L.transport_rtp_cb(adapters[radio], bytes(pkt), size)
+        stride = 320
+        slot = np.zeros((1, 1, stride), np.uint8)
+        slot[0, 0, :len(pkt)] = np.frombuffer(bytes(pkt), np.uint8)
+        _, _, info = orc.depayload(slot, np.array([[size]], np.uint16), [radio], n=256)
+        fl = int(info["flags"][0, 0])
+        if size < 12 or (fl & 0x40) or (fl & 0x80):              # runt / oversize: buffers untouched
+            assert (a.payload_bufSize, bytes(a.payload_buff)) == before
+            continue
+        assert a.payload_bufSize == int(info["payload_len"][0, 0]) == size - hdr
+        assert bytes(a.payload_buff[: size - hdr]) == bytes(pkt[hdr:size])
+        assert a.last_rx_pt == int(info["pt"][0, 0])
+        if radio and pt in (0, 8, 18, 123):
+            assert socket.ntohl(a.ed137_value) == int(info["ed137"][0, 0])
+        assert a.rtpAudio == (0 if pt == 123 else 1)
+    # TX side: silence probe counter and size guards, still no instance
+    sil = hu.rtp_packet(8, 1, bytes([0xD5]) * 160, radio=False)
+    for i in range(3):
+        assert L.transport_send_rtp(adapters[0], sil, len(sil)) == 0 and adapters[0].contents.rtpFalse == i + 1
+    assert L.transport_send_rtp(adapters[0], hu.rtp_packet(8, 2, bytes(160), radio=False), 172) == 0
+    assert adapters[0].contents.rtpFalse == 0
+    assert L.transport_send_rtp(adapters[0], sil, 300) == -22 and L.transport_send_rtp(adapters[0], sil, 5) == -22
+    for a in adapters.values():
+        L.igdsp_host_adapter_free(a)
