@@ -473,3 +473,56 @@ def test_fuzz_shapes_against_oracle(ctx, orc):
                 assert int(agg[f]) == int(res[k][f]), (case, f)
             assert agg["peak_slot"].tolist() == res[k]["peak_slot"].tolist(), case
     ctx.set_variant(0)
+
+
+# ----------------------------------------------------------------------------- sharding (config #4 shape)
+def test_channel_sharding_invariance(ctx, orc):
+    """BASELINE configs[3] logic on one GPU: the G ranks' shards (contiguous channel ranges of the global
+    [F][C][160] array, generated shard-invariantly) processed one after another give exactly the records of the
+    unsharded run, and their aggregates SUM to its aggregate with each rank's peak alone in its slot."""
+    from igate4xsoftphonedsp_amd import dist as igdist
+
+    torch = gu.torch_cuda()
+    C_, F_, n, G = 4096 + 64, 6, 160, 4
+    codec = np.where((np.arange(C_) // 3) & 1, 8, 0).astype(np.uint8)
+    full = orc.gen_uniform(F_ * C_ * n).reshape(F_, C_, n)
+    st_full, _, agg_full = gu.run_decode_meter(ctx, full, codec, want_agg=True, rank=0)
+    vec = np.zeros((capi.AGG_WORDS,), np.uint64)
+    for g in range(G):
+        lo, hi = igdist.channel_range(C_, g, G)
+        d_pl = torch.empty((F_, hi - lo, n), dtype=torch.uint8, device="cuda")
+        for f in range(F_):                                    # what bench.py does per rank
+            ctx.gen_uniform(d_pl[f], (hi - lo) * n, first_byte=(f * C_ + lo) * n)
+        torch.cuda.synchronize()
+        shard = d_pl.cpu().numpy()
+        assert np.array_equal(shard, full[:, lo:hi, :])
+        st, _, agg = gu.run_decode_meter(ctx, shard, codec[lo:hi], want_agg=True, rank=g)
+        for fld in ("sumsq", "peak", "byte_mean", "flags"):
+            assert np.array_equal(st[fld], st_full[fld][:, lo:hi]), (g, fld)
+        vec += np.frombuffer(agg.tobytes(), np.uint64)        # the all-reduce(SUM) of SURVEY 8(e)
+    node = igdist.node_view(torch.from_numpy(vec.view(np.int64)))
+    assert node["sumsq"] == int(agg_full["sumsq"]) and node["frames"] == C_ * F_ and node["samples"] == C_ * F_ * n
+    assert node["peak"] == int(st_full["peak"].max()) and node["byte_mean_sum"] == int(agg_full["byte_mean_sum"])
+    assert sorted(int(x) for x in vec[6:6 + G]) == sorted(int(st_full["peak"][:, slice(*igdist.channel_range(C_, g, G))].max()) for g in range(G))
+
+
+def test_half_million_channels_one_launch(ctx, orc):
+    """524 288 channels (BASELINE configs[3] total) in one launch on one GPU: 32-bit frame indexing, channel wrap
+    and the work queue at 8x the headline channel count; sampled frames against the oracle."""
+    torch = gu.torch_cuda()
+    C_, F_, n = 524288, 16, 160
+    d_pl = torch.empty((F_ * C_ * n,), dtype=torch.uint8, device="cuda")
+    ctx.gen_uniform(d_pl, d_pl.numel(), seed=5)
+    codec = np.where(np.arange(C_) % 5 == 0, 8, 0).astype(np.uint8)
+    d_st, d_agg = gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.dev_zeros(capi.AGGREGATE.itemsize)
+    ctx.decode_meter(d_pl, gu.to_dev(codec), C_, F_, n, d_st, agg=d_agg)
+    torch.cuda.synchronize()
+    st = gu.to_host(d_st, capi.FRAME_STATS)
+    agg = gu.to_host(d_agg, capi.AGGREGATE)[0]
+    assert int(agg["frames"]) == C_ * F_ and int(agg["sumsq"]) == int(st["sumsq"].sum(dtype=np.uint64))
+    rng = np.random.default_rng(1)
+    for fi in np.unique(np.concatenate([[0, C_ * F_ - 1], rng.integers(0, C_ * F_, 1500)])):
+        c = int(fi) % C_
+        e = orc.decode_meter(orc.gen_uniform(n, seed=5, first_byte=int(fi) * n).reshape(1, 1, n), [int(codec[c])])[0, 0]
+        g = st[fi]
+        assert (int(g["sumsq"]), int(g["peak"]), int(g["byte_mean"]), int(g["flags"])) == (int(e["sumsq"]), int(e["peak"]), int(e["byte_mean"]), int(e["flags"])), fi
