@@ -183,7 +183,7 @@ int igdsp_device_info(const igdsp_ctx *ctx, int *device, int *compute_units, cha
 
 int igdsp_set_variant(igdsp_ctx *ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant > 2) return IGDSP_EINVAL;
+    if (!ctx || variant < 0 || variant > 3) return IGDSP_EINVAL;
     ctx->variant = variant;
     return IGDSP_OK;
 }

@@ -633,6 +633,110 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
 }
 
 // ============================================================================
+// Variant 3 — "fat waves": the same super-chunk pipeline with FOUR super-chunks of lookahead per wave.
+// 8 waves/block at up to 256 VGPRs: forty 16-byte piece registers per lane (4 x 10 KiB in flight per
+// wave, 320 KiB per CU instead of 160 KiB) — the experiment for the "16 waves/CU recycle their ten
+// load registers too slowly" bound of variant 2.  Static interleaved distribution; item k of a wave
+// lives in register set k % 4 and each piece is re-loaded from item k + 4 the moment it is folded.
+// ============================================================================
+constexpr int kFatWaves = 8;
+constexpr int kFatDepth = 4;
+
+template <bool AGG>
+__global__ __launch_bounds__(kFatWaves * 64) void k_meter_fat(
+    const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t n_frames,
+    igdsp_frame_stats *__restrict__ stats, igdsp_aggregate *agg, uint32_t rank)
+{
+    __shared__ uint2 lds[kLutEntries + kFatWaves * kStripEntries];
+    fill_lut(lds);
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2 *strip = lds + kLutEntries + wave * kStripEntries;
+    const uint32_t off = (lane & 31u) * 8u;
+    uint32_t fr[kLoadsPerChunk], pm[kLoadsPerChunk];
+#pragma unroll
+    for (int j = 0; j < kLoadsPerChunk; ++j) {
+        const uint32_t p = (uint32_t)j * 64u + lane;
+        fr[j] = p / 10u;
+        pm[j] = probe_mask(p - fr[j] * 10u);
+    }
+    const uint32_t n_super = n_frames / kSuperFrames;
+    const uint32_t stride = gridDim.x * kFatWaves;                 // items of one wave: first, first + stride, ...
+    const uint32_t first = blockIdx.x * kFatWaves + wave;
+    const uint4 *src16 = reinterpret_cast<const uint4 *>(payload);
+
+    uint64_t a_sumsq = 0;
+    uint32_t a_frames = 0, a_sil = 0, a_clip = 0, a_bm = 0, a_peak = 0;
+
+    uint4 X[kFatDepth][kLoadsPerChunk], Y[kFatDepth][kLoadsPerChunk];
+    uint32_t pt[kFatDepth];
+    auto item_or0 = [&](uint32_t k) { const uint32_t i = first + k * stride; return i < n_super ? i : 0u; };
+    auto fetch_pt = [&](uint32_t sidx) { return (uint32_t)codec[(sidx * (uint32_t)kSuperFrames + lane) % C]; };
+
+    if (first < n_super) {
+#pragma unroll
+        for (int s = 0; s < kFatDepth; ++s) {
+            const uint32_t i = item_or0((uint32_t)s);
+            pt[s] = fetch_pt(i);
+            const uint4 *p0 = src16 + (i * (uint32_t)kStripEntries + lane);
+#pragma unroll
+            for (int j = 0; j < kLoadsPerChunk; ++j) X[s][j] = ld_stream(p0 + j * 64);
+#pragma unroll
+            for (int j = 0; j < kLoadsPerChunk; ++j) Y[s][j] = ld_stream(p0 + kPiecesPerChunk + j * 64);
+        }
+        for (uint32_t k0 = 0;; k0 += kFatDepth) {
+            bool done = false;
+#pragma unroll
+            for (int s = 0; s < kFatDepth; ++s) {
+                const uint32_t sidx = first + (k0 + (uint32_t)s) * stride;
+                if (sidx >= n_super) { done = true; break; }
+                const uint32_t s_load = item_or0(k0 + (uint32_t)s + kFatDepth);
+                const uint32_t f0 = sidx * kSuperFrames;
+                const bool my_alaw = pt[s] == IGDSP_PT_PCMA;
+                const uint64_t amask = __ballot(my_alaw);
+                const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
+                uint32_t lm0[kLoadsPerChunk], lm1[kLoadsPerChunk];
+#pragma unroll
+                for (int j = 0; j < kLoadsPerChunk; ++j) {
+                    lm0[j] = (uint32_t)__builtin_amdgcn_sbfe(am_lo, fr[j], 1) & 0x80808080u;
+                    lm1[j] = (uint32_t)__builtin_amdgcn_sbfe(am_hi, fr[j], 1) & 0x80808080u;
+                }
+                const uint4 *nsrc = src16 + (s_load * (uint32_t)kStripEntries + lane);
+                pt[s] = fetch_pt(s_load);
+                process_half<false>(lds, strip, X[s], lm0, pm, off, lane, nullptr, nsrc);
+                process_half<false>(lds, strip + kPiecesPerChunk, Y[s], lm1, pm, off, lane, nullptr, nsrc + kPiecesPerChunk);
+                wave_lds_fence();
+                {
+                    const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kPiecesPerFrame);
+                    uint64_t sm = 0;
+                    uint32_t peak = 0, bsum = 0, fail = 0;
+#pragma unroll
+                    for (int i = 0; i < kPiecesPerFrame / 2; ++i) {
+                        const uint4 v = row[i];
+                        sm += (uint64_t)(v.x + v.z);
+                        peak = max(max(peak, v.y & 0x7FFFu), v.w & 0x7FFFu);
+                        bsum += ((v.y >> 16) & 0x7FFFu) + ((v.w >> 16) & 0x7FFFu);
+                        fail |= v.y | v.w;
+                    }
+                    uint32_t bm, fl;
+                    st_stream(reinterpret_cast<uint4 *>(stats + (f0 + lane)), pack_stats160(sm, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl));
+                    if (AGG) {
+                        a_sumsq += sm << 4; a_frames += 1u; a_sil += (fl & IGDSP_FLAG_SILENT) ? 1u : 0u;
+                        a_clip += (fl & IGDSP_FLAG_CLIPPED) ? 1u : 0u; a_bm += bm; a_peak = max(a_peak, peak);
+                    }
+                }
+                wave_lds_fence();
+            }
+            if (done) break;
+        }
+    }
+    if (AGG && agg != nullptr)
+        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kFatWaves, a_sumsq, (uint64_t)a_frames * kFrame, a_frames,
+                         a_sil, a_clip, a_bm, a_peak);
+}
+
+// ============================================================================
 // Fused packet path — k_meter_rtp64: depayload + decode + meter in one pass over 192-byte packet slots
 // (include/igdsp.h, igdsp_decode_meter_rtp).  Same machinery as k_meter_chunk64 with 12 pieces per
 // slot instead of 10: pieces 0 and 1 of a slot are {size, pad, RTP bytes 0-3} and {RTP bytes 4-19}; they
@@ -1463,7 +1567,15 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
     // tuned path takes the whole super-chunks (64 frames); the < 64 remaining frames, and every shape it
     // does not cover, go through the general wave-per-frame kernel on the same stream.
     uint32_t done = 0;
-    if (variant != 1 && chunk_ok && n_frames >= (uint32_t)kSuperFrames) {
+    if (variant == 3 && chunk_ok && pcm == nullptr && n_frames >= (uint32_t)kSuperFrames) {
+        const uint32_t n_super = n_frames / kSuperFrames;
+        done = n_super * kSuperFrames;
+        const uint32_t grid = blocks_for(n_super, kFatWaves, (uint32_t)cfg.compute_units);
+        if (agg) hipLaunchKernelGGL((k_meter_fat<true>), dim3(grid), dim3(kFatWaves * 64), 0, s, payload, codec, C, done, stats, agg, rank);
+        else     hipLaunchKernelGGL((k_meter_fat<false>), dim3(grid), dim3(kFatWaves * 64), 0, s, payload, codec, C, done, stats, agg, rank);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    } else if (variant != 1 && chunk_ok && n_frames >= (uint32_t)kSuperFrames) {
         const uint32_t n_super = n_frames / kSuperFrames;
         done = n_super * kSuperFrames;
         uint64_t *nodiag = nullptr;

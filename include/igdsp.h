@@ -323,7 +323,8 @@ int igdsp_stream_read(igdsp_ctx *ctx, const void *d_src, size_t bytes, uint64_t 
 
 /* Kernel variant selection for experiments (0 = default tuned path).
  *   1 = one wavefront per channel-frame (40 lanes x dword), the literal north_star mapping
- *   2 = chunked: one wavefront per 32 consecutive frames, 16 B/lane loads (default for n == 160) */
+ *   2 = chunk64: one wavefront per 64 consecutive frames, 16 B/lane loads, 16 waves/CU (default for n == 160)
+ *   3 = chunk64 with four super-chunks of lookahead per wave, 8 waves/CU (meter-only; experiment) */
 int igdsp_set_variant(igdsp_ctx *ctx, int variant);
 
 #ifdef __cplusplus

@@ -29,7 +29,7 @@ def _edge_frames(n=160):
 
 
 # ----------------------------------------------------------------------------- a1/a3/a5/a7
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_all_codes_both_laws_bit_exact(ctx, orc, variant):
     """Every G.711 code, both laws, every lane/byte position: PCM and stats bit-exact."""
     ctx.set_variant(variant)
@@ -48,7 +48,7 @@ def test_all_codes_both_laws_bit_exact(ctx, orc, variant):
     ctx.set_variant(0)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_config2_4096ch_uniform_and_edges(ctx, orc, variant):
     """BASELINE config #2: 4 096 ch, F=16, D-uniform + D-edge, PCM store on, every int16 compared."""
     ctx.set_variant(variant)
@@ -378,11 +378,14 @@ def test_full_size_sampled_frames_vs_oracle(big, orc):
 def test_full_size_variants_agree(ctx, big):
     """wave-per-frame (variant 1) and chunk32 (variant 2) produce identical records at full size."""
     torch = gu.torch_cuda()
-    d_st1 = gu.dev_zeros(big["F"] * big["C"] * 16, 0xEE)
+    d_st1, d_st3 = gu.dev_zeros(big["F"] * big["C"] * 16, 0xEE), gu.dev_zeros(big["F"] * big["C"] * 16, 0xEE)
     ctx.set_variant(1)
     ctx.decode_meter(big["d_pl"], big["d_cd"], big["C"], big["F"], big["n"], d_st1, stream=torch.cuda.current_stream().cuda_stream)
+    ctx.set_variant(3)
+    ctx.decode_meter(big["d_pl"], big["d_cd"], big["C"], big["F"], big["n"], d_st3, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     ctx.set_variant(0)
+    assert torch.equal(d_st3, big["d_st"])                     # the two chunk64 forms share every instruction that forms a record
     a, b = gu.to_host(d_st1, capi.FRAME_STATS), gu.to_host(big["d_st"], capi.FRAME_STATS)
     for f in ("sumsq", "peak", "byte_mean", "flags"):          # every integer field bit-identical
         assert np.array_equal(a[f], b[f]), f
