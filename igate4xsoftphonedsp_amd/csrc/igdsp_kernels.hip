@@ -45,8 +45,12 @@ __device__ __forceinline__ uint32_t alaw_abs(uint32_t code)
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 ld_stream(const uint4 *p)
 {
+#ifdef IGDSP_AB_PLAIN_LOADS
+    return *p;                                                  // A/B: default cache policy
+#else
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
+#endif
 }
 
 // write-once 16-byte store (records / PCM are never re-read by this launch)
