@@ -256,6 +256,10 @@ def main():
     }
 
     if not args.no_stream_calib:
+        # two bare calibration kernels on the same buffer: a read-only stream, and the meter kernel's exact
+        # traffic pattern (10 KiB read + 1 KiB record store per super-chunk) with no per-sample work
+        import ctypes as CT
+
         sink = torch.zeros((1,), dtype=torch.int64, device="cuda")
         tm = ctx.timer()
         for _ in range(3):
@@ -265,6 +269,19 @@ def main():
             ctx.stream_read(d_pl, d_pl.numel(), sink, stream=hs)
         tm.stop(hs)
         out["roofline"]["stream_read_GBs"] = round(d_pl.numel() * 10 / (tm.elapsed_ms() * 1e-3) / 1e9, 1)
+        fn = ctx.L.igdsp_internal_stream_rw
+        fn.restype = CT.c_int
+        fn.argtypes = [CT.c_void_p, CT.c_void_p, CT.c_size_t, CT.c_void_p, CT.c_void_p]
+        for _ in range(3):
+            fn(ctx.h, d_pl.data_ptr(), d_pl.numel(), d_st.data_ptr(), hs)
+        tm.start(hs)
+        for _ in range(10):
+            fn(ctx.h, d_pl.data_ptr(), d_pl.numel(), d_st.data_ptr(), hs)
+        tm.stop(hs)
+        rw_ms = tm.elapsed_ms() / 10
+        out["roofline"]["same_traffic_stream_ms"] = round(rw_ms, 4)
+        if args.mode == "meter":
+            out["roofline"]["frac_of_same_traffic_stream"] = round(rw_ms / kern_avg_ms, 4)
 
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(traffic_file):

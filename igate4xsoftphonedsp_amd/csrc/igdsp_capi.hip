@@ -470,6 +470,16 @@ int igdsp_internal_encode_table(igdsp_ctx *ctx, const int16_t *d_pcm, const uint
     return IGDSP_OK;
 }
 
+// Calibration-only (not in include/igdsp.h): bare load/store kernel with the meter kernel's exact traffic
+// (10 KiB read + 1 KiB record store per super-chunk); d_dst needs bytes / 10 bytes.
+int igdsp_internal_stream_rw(igdsp_ctx *ctx, const void *d_src, size_t bytes, void *d_dst, void *stream)
+{
+    if (!ctx || !d_src || !d_dst || (reinterpret_cast<uintptr_t>(d_src) & 15u) || (reinterpret_cast<uintptr_t>(d_dst) & 15u)) return IGDSP_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_stream_rw(cfg_of(ctx), d_src, bytes, d_dst, pick(ctx, stream)));
+    return IGDSP_OK;
+}
+
 // Diagnostic-only (not in include/igdsp.h): cycle stamps of the chunk32 kernel, 8 x u64 per wavefront
 // {t_begin, t_lut_ready, t_end, sum load-wait, sum process, iterations, sum frame-reduce, xcc id}.
 int igdsp_internal_diag_chunk32(igdsp_ctx *ctx, const uint8_t *d_payload, const uint8_t *d_codec, uint32_t C, uint32_t F,

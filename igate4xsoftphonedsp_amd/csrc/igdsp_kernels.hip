@@ -55,7 +55,7 @@ __device__ __forceinline__ uint4 ld_stream(const uint4 *p)
 
 // write-once 16-byte store (records / PCM are never re-read by this launch)
 #ifndef IGDSP_NT_STORE
-#define IGDSP_NT_STORE 1
+#define IGDSP_NT_STORE 0      // cached stores measured ~1 % faster than nontemporal for the 1 KiB record blocks
 #endif
 __device__ __forceinline__ void st_stream(uint4 *p, const uint4 v)
 {
@@ -314,7 +314,12 @@ __device__ __forceinline__ uint2 lut_at(const uint2 *lut, uint32_t t, uint32_t o
 {
     // byte address = off | (byte_k(t) << 8); v_perm_b32: sel bytes 4..7 pick from t, 0..3 from off, 0x0C = 0x00
     const uint32_t addr = __builtin_amdgcn_perm(t, off, sel);
+#ifdef IGDSP_AB_NOLUT
+    (void)lut;
+    return make_uint2(addr >> 3, addr & 0x7FFFu);             // A/B only: same VALU, no LDS read (results wrong)
+#else
     return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(lut) + addr);
+#endif
 }
 
 __device__ __forceinline__ uint32_t pack_pcm(uint32_t w, uint32_t k, uint32_t ax0, uint32_t ax1)
@@ -380,6 +385,16 @@ __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half
     // `refill` = this lane's first piece of the NEXT super-chunk's same half: piece j's register is
     // reloaded the moment piece j has been folded, so the five loads trickle out evenly and get
     // most of an iteration of lead time.
+#ifdef IGDSP_AB_NOCOMPUTE
+    // A/B only: the kernel's exact load / refill / strip / store pattern with the per-sample work removed
+#pragma unroll
+    for (int j = 0; j < kLoadsPerChunk; ++j) {
+        strip_half[j * 64 + lane] = make_uint2(d[j].x ^ d[j].y, (d[j].z ^ d[j].w) & 0x7FFFFFFFu);
+        d[j] = ld_stream(refill + j * 64);
+    }
+    (void)lut; (void)lm; (void)pm; (void)off; (void)pcm_half;
+    return;
+#endif
     uint2 e[2][8];
     uint32_t wa[2], wb[2];
     auto issue = [&](int u) {
@@ -1531,25 +1546,22 @@ __global__ __launch_bounds__(kBlockThreads) void k_stream_read(const uint4 *__re
     if ((threadIdx.x & 63u) == 0u && v == 0x9E3779B9u) atomicAdd((unsigned long long *)sink, 1ull);   // keeps the loads live
 }
 
-// Same calibration with the meter kernel's exact access pattern: a wave owns a 10 KiB contiguous
-// super-chunk (ten 1 KiB loads), 16 waves per block take 16 adjacent super-chunks, blocks stride by G.
-__global__ __launch_bounds__(kBlockThreads) void k_stream_read_chunked(const uint4 *__restrict__ src, uint32_t n_super,
-                                                                       uint64_t *__restrict__ sink)
+// Calibration of the meter kernel's full traffic pattern with nothing else: every wave reads 10 KiB super-chunks
+// (ten 1 KiB loads, 16 adjacent super-chunks per block) and stores one 1 KiB record block per super-chunk —
+// what a perfect implementation of the same bytes in / bytes out would take on this memory system.
+__global__ __launch_bounds__(kBlockThreads) void k_stream_rw(const uint4 *__restrict__ src, uint32_t n_super, uint4 *__restrict__ dst)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint4 acc = make_uint4(0, 0, 0, 0);
     for (uint32_t b = blockIdx.x; b * kWavesPerBlock + wave < n_super; b += gridDim.x) {
-        const uint4 *p = src + ((uint64_t)(b * kWavesPerBlock + wave) * 640u + lane);
-        uint4 v[10];
+        const uint32_t sidx = b * kWavesPerBlock + wave;
+        const uint4 *p = src + ((uint64_t)sidx * 640u + lane);
+        uint4 v[10], acc = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 10; ++j) v[j] = ld_stream(p + j * 64);
 #pragma unroll
         for (int j = 0; j < 10; ++j) { acc.x ^= v[j].x; acc.y ^= v[j].y; acc.z ^= v[j].z; acc.w ^= v[j].w; }
+        dst[(uint64_t)sidx * 64u + lane] = acc;
     }
-    uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) r ^= (uint32_t)__shfl_xor((int)r, m, 64);
-    if (lane == 0u && r == 0x9E3779B9u) atomicAdd((unsigned long long *)sink, 1ull);
 }
 
 // ============================================================================
@@ -1714,16 +1726,18 @@ hipError_t launch_gen_uniform(uint8_t *out, uint64_t n_bytes, uint64_t seed, uin
     return hipGetLastError();
 }
 
+hipError_t launch_stream_rw(const LaunchCfg &cfg, const void *src, size_t bytes, void *dst, hipStream_t s)
+{
+    const uint32_t n_super = (uint32_t)(bytes / 10240u);
+    if (n_super == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_stream_rw, dim3(cfg.compute_units), dim3(kBlockThreads), 0, s, reinterpret_cast<const uint4 *>(src), n_super,
+                       reinterpret_cast<uint4 *>(dst));
+    return hipGetLastError();
+}
+
 hipError_t launch_stream_read(const LaunchCfg &cfg, const void *src, size_t bytes, uint64_t *sink, hipStream_t s)
 {
     if (bytes < 16) return hipSuccess;
-    if (const char *e = getenv("IGDSP_STREAM_MODE")) {
-        if (atoi(e) == 1) {
-            hipLaunchKernelGGL(k_stream_read_chunked, dim3(cfg.compute_units), dim3(kBlockThreads), 0, s,
-                               reinterpret_cast<const uint4 *>(src), (uint32_t)(bytes / 10240u), sink);
-            return hipGetLastError();
-        }
-    }
     hipLaunchKernelGGL(k_stream_read, dim3(cfg.compute_units), dim3(kBlockThreads), 0, s,
                        reinterpret_cast<const uint4 *>(src), (uint64_t)(bytes >> 4), sink);
     return hipGetLastError();
