@@ -54,7 +54,8 @@ struct igdsp_ctx {
     uint16_t *d_len = nullptr;
     uint8_t *d_pt = nullptr;
     igdsp_frame_stats *d_stats = nullptr;
-    igdsp_frame_stats *h_stats = nullptr;               // pinned
+    igdsp_frame_stats *h_stats = nullptr;               // pinned: last metered record per channel
+    igdsp_frame_stats *h_fresh = nullptr;               // pinned: this flush's records (EMPTY where nothing was staged)
     igdsp_chan_hold *d_hold = nullptr;
     igdsp_chan_hold *h_hold = nullptr;                  // pinned
     std::vector<uint32_t> frames_seen;
@@ -131,6 +132,7 @@ int igdsp_create(igdsp_ctx **out, int device, uint32_t max_channels)
     ok = ok && hipHostMalloc((void **)&ctx->h_up_len, max_channels * sizeof(uint16_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_up_pt, max_channels, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_stats, max_channels * sizeof(igdsp_frame_stats), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&ctx->h_fresh, max_channels * sizeof(igdsp_frame_stats), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_hold, max_channels * sizeof(igdsp_chan_hold), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_slab, slab) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_len, max_channels * sizeof(uint16_t)) == hipSuccess;
@@ -162,7 +164,7 @@ int igdsp_destroy(igdsp_ctx *ctx)
     if (!ctx) return IGDSP_OK;                       // tolerate NULL like the reference's setters (TransportAdapter.cpp:135-223)
     if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
-    void *hosts[] = {ctx->h_slab, ctx->h_len, ctx->h_pt, ctx->h_up, ctx->h_up_len, ctx->h_up_pt, ctx->h_stats, ctx->h_hold};
+    void *hosts[] = {ctx->h_slab, ctx->h_len, ctx->h_pt, ctx->h_up, ctx->h_up_len, ctx->h_up_pt, ctx->h_stats, ctx->h_fresh, ctx->h_hold};
     for (void *p : hosts) if (p) (void)hipHostFree(p);
     void *devs[] = {ctx->d_slab, ctx->d_len, ctx->d_pt, ctx->d_stats, ctx->d_hold, ctx->d_queues};
     for (void *p : devs) if (p) (void)hipFree(p);
@@ -261,8 +263,8 @@ int igdsp_flush(igdsp_ctx *ctx, uint32_t *n_frames_out)
     HIP_TRY(ctx, launch_decode_meter(cfg_of(ctx), 1, ctx->d_slab, ctx->d_pt, ctx->d_len, nch, 1, kSlot, ctx->d_stats, nullptr, nullptr, 0, s));
     HIP_TRY(ctx, launch_hold_update(ctx->d_stats, ctx->d_len, nch, 1, kSlot, ctx->d_hold, nullptr, s));
     // a channel with nothing staged keeps its previous level: copy to a scratch and merge on the host
-    std::vector<igdsp_frame_stats> fresh(nch);
-    HIP_TRY(ctx, hipMemcpyAsync(fresh.data(), ctx->d_stats, nch * sizeof(igdsp_frame_stats), hipMemcpyDeviceToHost, s));
+    igdsp_frame_stats *fresh = ctx->h_fresh;
+    HIP_TRY(ctx, hipMemcpyAsync(fresh, ctx->d_stats, nch * sizeof(igdsp_frame_stats), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hold, ctx->d_hold, nch * sizeof(igdsp_chan_hold), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     for (uint32_t c = 0; c < nch; ++c)

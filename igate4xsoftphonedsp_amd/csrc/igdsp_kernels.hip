@@ -1045,8 +1045,7 @@ __global__ __launch_bounds__(256) void k_encode_v8(const int16_t *__restrict__ p
                                                    uint32_t C, uint32_t n, uint64_t n_groups, uint8_t *__restrict__ out)
 {
     const uint32_t groups_per_frame = n >> 3;
-    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (uint64_t)gridDim.x * blockDim.x) {
-        const uint4 d = ld_stream(reinterpret_cast<const uint4 *>(pcm) + g);
+    auto encode_group = [&](uint64_t g, const uint4 d) {
         const uint32_t c = (uint32_t)((g / groups_per_frame) % C);
         const EncK k = enc_consts<VARIANT>(codec[c] == IGDSP_PT_PCMA);
         const uint32_t w[4] = {d.x, d.y, d.z, d.w};
@@ -1060,7 +1059,17 @@ __global__ __launch_bounds__(256) void k_encode_v8(const int16_t *__restrict__ p
         o.x = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
         o.y = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
         reinterpret_cast<uint2 *>(out)[g] = o;
+    };
+    // four independent 16-byte loads in flight per lane (one per quarter of the grid-stride step)
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4 *src = reinterpret_cast<const uint4 *>(pcm);
+    for (; g + 3u * stride < n_groups; g += 4u * stride) {
+        const uint4 d0 = ld_stream(src + g), d1 = ld_stream(src + g + stride), d2 = ld_stream(src + g + 2u * stride),
+                    d3 = ld_stream(src + g + 3u * stride);
+        encode_group(g, d0); encode_group(g + stride, d1); encode_group(g + 2u * stride, d2); encode_group(g + 3u * stride, d3);
     }
+    for (; g < n_groups; g += stride) encode_group(g, ld_stream(src + g));
 }
 
 template <int VARIANT>
