@@ -190,6 +190,11 @@ def main():
                 dist.all_reduce(aggs[b], op=dist.ReduceOp.SUM)
                 ev_c[b].record(comm_s)
 
+    if world > 1:                                  # communicator / channel setup is not part of any step (holds for --warmup 0 too)
+        prime = torch.zeros((capi.AGG_WORDS,), dtype=torch.int64, device="cuda")
+        with torch.cuda.stream(comm_s):
+            dist.all_reduce(prime, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
