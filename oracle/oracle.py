@@ -20,6 +20,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libigdsp_oracle.so")
 _REF_WAV_PATH = os.path.join(_HERE, "_ref", "libref_wavwriter.so")
+_REF_METER_PATH = os.path.join(_HERE, "_ref", "libref_audiometer.so")
 
 FRAME_STATS = np.dtype(
     [("sumsq", "<u8"), ("rms", "<f4"), ("peak", "<u2"), ("byte_mean", "u1"), ("flags", "u1")], align=True
@@ -51,7 +52,7 @@ def build(force: bool = False) -> str:
         os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "igdsp_oracle.c"))
     ):
         subprocess.run(["make", "-C", _HERE, "-s", "_build/libigdsp_oracle.so"], check=True)
-    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF_WAV_PATH)):
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF_WAV_PATH) or not os.path.exists(_REF_METER_PATH)):
         subprocess.run(["make", "-C", _HERE, "-s", "ref"], check=True)
     return _LIB_PATH
 
@@ -283,3 +284,19 @@ def ref_wav_record(tmpdir: str, payloads: np.ndarray, rate: int = 8000) -> bytes
     assert len(new) == 1, new
     with open(os.path.join(sub, new[0]), "rb") as fh:
         return fh.read()
+
+
+def ref_audiometer_available() -> bool:
+    return os.path.exists(_REF_METER_PATH)
+
+
+def ref_audiometer_percent(levels, card: str = "igdsp") -> list:
+    """Feed integer levels through the REAL reference AudioMeter::getAudioLevel() (oracle/_ref, built from
+    /root/reference/audiometer.cpp + its moc output) via its FIFO; returns the percents it emitted."""
+    L = C.CDLL(_REF_METER_PATH)
+    L.ref_audiometer_percent.restype = C.c_int
+    lv = np.ascontiguousarray(levels, dtype=np.int32)
+    out = np.zeros_like(lv)
+    n = L.ref_audiometer_percent(f"{card}{os.getpid()}".encode(), _p(lv), lv.size, _p(out))
+    assert n == lv.size, (n, lv.size)
+    return out.tolist()

@@ -94,6 +94,15 @@ def main():
     with open(os.path.join(HERE, "config1_4ch_50f.json"), "w") as fh:
         json.dump(meta, fh, indent=1, sort_keys=True)
 
+    # --- percent scale from the REAL AudioMeter (audiometer.cpp:16-34 through its FIFO)
+    if not orc.ref_audiometer_available():
+        raise SystemExit("oracle/_ref/libref_audiometer.so missing: run `make -C oracle` (needs Qt5 moc under /opt/conda)")
+    levels = [0, 1, 299, 300, 301, 599, 600, 14999, 15000, 29999, 30000, 30299, 30300, 32124, 32256, 32767, 65535, 123456, -1, -299, -300, -30000]
+    levels += list(range(0, 33000, 997))
+    with open(os.path.join(HERE, "audiometer_percent.json"), "w") as fh:
+        json.dump({"source": "AudioMeter::getAudioLevel() of /root/reference/audiometer.cpp (real object, via /tmp/capturefifo<card>)",
+                   "levels": levels, "percent": orc.ref_audiometer_percent(levels)}, fh)
+
     # --- splitmix64 known answers (public reference values for seed 0 stream: 1234567 variant below is ours)
     sm = {"splitmix64(0)": str(orc.lib().orc_splitmix64(0)), "first16_uniform_seed": orc.gen_uniform(16).tolist()}
     with open(os.path.join(HERE, "prng.json"), "w") as fh:

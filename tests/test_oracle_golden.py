@@ -115,6 +115,19 @@ def test_percent_scale(orc):
         assert orc.percent(v) == p
 
 
+def test_percent_scale_against_real_audiometer(orc, golden_dir):
+    """The fixture holds what the REAL reference AudioMeter emitted (object code built from
+    /root/reference/audiometer.cpp); the restated formula must agree on every level, live too when oracle/_ref exists."""
+    with open(os.path.join(golden_dir, "audiometer_percent.json")) as fh:
+        g = json.load(fh)
+    assert len(g["levels"]) == len(g["percent"]) > 50
+    for v, p in zip(g["levels"], g["percent"]):
+        assert orc.percent(v) == p, v
+    if orc.ref_audiometer_available():
+        live = [7, 300, 29999, 31000, -450]
+        assert orc.ref_audiometer_percent(live) == [orc.percent(v) for v in live]
+
+
 def test_config1_against_real_wavwriter_and_audioop(orc, golden_dir):
     g = np.load(os.path.join(golden_dir, "config1_4ch_50f.npz"))
     with open(os.path.join(golden_dir, "config1_4ch_50f.json")) as fh:
