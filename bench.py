@@ -153,8 +153,18 @@ def main():
         d_slots[:, :, 12] = 0x90
         d_slots[:, :, 13] = 0
         d_info = torch.empty((F_ * C_,), dtype=torch.int64, device="cuda")
-    if args.mode == "roundtrip":                                          # BASELINE configs[4]: mixed A-law / mu-law
+    if args.mode == "roundtrip":                                          # BASELINE configs[4]: mixed A-law / mu-law, D-speech
         d_cd[1::2] = 8
+        # D-speech: two-tone + noise, amplitude 1000*(1 + c mod 30), encoded with the oracle's encoder.
+        # The generator is CPU test infrastructure, so a [F][480][160] tile (16 amplitude periods, both laws) is
+        # generated once and replicated across the 65 536 channels on the device — synthetic data either way.
+        from oracle import oracle as orc
+
+        tile_c = 480
+        tile = orc.gen_speech(tile_c, F_, n, (np.arange(tile_c) & 1).astype(np.uint8) * 8)
+        d_tile = torch.from_numpy(tile).cuda()
+        d_pl.copy_(d_tile[:, torch.arange(C_, device="cuda") % tile_c, :])
+        del d_tile
         d_out = torch.empty_like(d_pl)
         d_hold = torch.zeros((C_ * 4,), dtype=torch.int64, device="cuda")
         ctx.hold_reset(d_hold, C_, stream=hs)
@@ -244,8 +254,9 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": f"{C_} ch/GPU x {F_} frames x {n} samples mu-law decode+meter ({args.mode}), "
-                        f"device-resident {d_pl.numel() / 1e9:.2f} GB/GPU, D-uniform seed 0x20241218",
+            "workload": f"{C_} ch/GPU x {F_} frames x {n} samples {'mixed A-law/mu-law' if args.mode == 'roundtrip' else 'mu-law'} "
+                        f"decode+meter ({args.mode}), device-resident {d_pl.numel() / 1e9:.2f} GB/GPU, "
+                        f"{'D-speech tile x channels' if args.mode == 'roundtrip' else 'D-uniform seed 0x20241218'}",
             "channels_per_gpu": C_, "channels_total": C_total, "frames_per_launch": F_, "samples_per_frame": n,
             "sharding": "contiguous channel ranges, no data-path collective; one 112 B all-reduce per launch" if world > 1 else "single GPU",
             "kernel_variant": args.variant,
