@@ -1072,6 +1072,43 @@ __global__ __launch_bounds__(256) void k_encode_v8(const int16_t *__restrict__ p
     for (; g < n_groups; g += stride) encode_group(g, ld_stream(src + g));
 }
 
+// Same 8-samples-per-lane geometry with the table-driven compressor (2 x 16 384 one-byte cells in LDS, built per
+// block by enc_uni): ~8 VALU + one LDS byte read per sample instead of ~20 VALU, which moves the encode kernel from
+// VALU-bound towards the copy-like HBM bound.  Persistent blocks so the 32 KiB table is built 2 x CUs times only.
+template <int VARIANT>
+__global__ __launch_bounds__(1024) void k_encode_v8_table(const int16_t *__restrict__ pcm, const uint8_t *__restrict__ codec,
+                                                          uint32_t C, uint32_t n, uint64_t n_groups, uint8_t *__restrict__ out)
+{
+    __shared__ uint8_t tab[2 * kEncCells];
+    fill_enc_table<VARIANT>(tab);
+    __syncthreads();
+    const uint32_t groups_per_frame = n >> 3;
+    auto encode_group = [&](uint64_t g, const uint4 d) {
+        const uint32_t c = (uint32_t)((g / groups_per_frame) % C);
+        const uint8_t *t = tab + (codec[c] == IGDSP_PT_PCMA ? kEncCells : 0);
+        const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+        uint32_t r[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r[2 * i] = t[enc_cell<VARIANT>((int)(int16_t)(w[i] & 0xFFFFu))];
+            r[2 * i + 1] = t[enc_cell<VARIANT>((int)(int16_t)(w[i] >> 16))];
+        }
+        uint2 o;
+        o.x = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+        o.y = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
+        reinterpret_cast<uint2 *>(out)[g] = o;
+    };
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4 *src = reinterpret_cast<const uint4 *>(pcm);
+    for (; g + 3u * stride < n_groups; g += 4u * stride) {
+        const uint4 d0 = ld_stream(src + g), d1 = ld_stream(src + g + stride), d2 = ld_stream(src + g + 2u * stride),
+                    d3 = ld_stream(src + g + 3u * stride);
+        encode_group(g, d0); encode_group(g + stride, d1); encode_group(g + 2u * stride, d2); encode_group(g + 3u * stride, d3);
+    }
+    for (; g < n_groups; g += stride) encode_group(g, ld_stream(src + g));
+}
+
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_encode_scalar(const int16_t *__restrict__ pcm, const uint8_t *__restrict__ codec,
                                                        uint32_t C, uint32_t n, uint64_t n_samples, uint8_t *__restrict__ out)
@@ -1655,7 +1692,12 @@ hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t
     const bool v8 = ((n & 7u) == 0u) && ((reinterpret_cast<uintptr_t>(pcm) & 15u) == 0u) &&
                     ((reinterpret_cast<uintptr_t>(out) & 7u) == 0u);
     const uint32_t cap = (uint32_t)cfg.compute_units * 8u;
-    if (v8) {
+    if (v8 && n_samples >= (1u << 22)) {                        // big batches: table-driven compressor, persistent blocks
+        const uint64_t groups = n_samples >> 3;
+        const uint32_t grid = blocks_for(groups, 1024, (uint32_t)cfg.compute_units * 2u);
+        if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_v8_table<IGDSP_ENC_G191>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, groups, out);
+        else                           hipLaunchKernelGGL((k_encode_v8_table<IGDSP_ENC_SUN16>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, groups, out);
+    } else if (v8) {
         const uint64_t groups = n_samples >> 3;
         const uint32_t grid = blocks_for(groups, 256, cap);
         if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_v8<IGDSP_ENC_G191>), dim3(grid), dim3(256), 0, s, pcm, codec, C, n, groups, out);

@@ -188,6 +188,20 @@ def test_table_driven_compressor_exhaustive(ctx, orc, variant):
     assert np.array_equal(gu.to_host(d_out, np.uint8, (F_, C_, n)), orc.encode(pcm, codec, variant))
 
 
+@pytest.mark.parametrize("variant", [capi.ENC_SUN16, capi.ENC_G191])
+def test_encode_large_batch_table_path(ctx, orc, variant):
+    """Batches of >= 4 M samples take the table-driven encode kernel: every int16 value x both laws, 64 times over."""
+    torch = gu.torch_cuda()
+    C_, F_, n = 64, 512, 256                       # 8.4 M samples
+    base = np.arange(-32768, 32768, dtype=np.int32).astype("<i2")
+    pcm = np.tile(base, C_ * F_ * n // base.size).reshape(F_, C_, n)
+    codec = np.where(np.arange(C_) % 2, 8, 0).astype(np.uint8)
+    d_out = gu.dev_zeros(F_ * C_ * n, 0xEE)
+    ctx.encode(gu.to_dev(pcm), gu.to_dev(codec), C_, F_, n, d_out, variant=variant)
+    torch.cuda.synchronize()
+    assert np.array_equal(gu.to_host(d_out, np.uint8, (F_, C_, n)), orc.encode(pcm, codec, variant))
+
+
 @pytest.mark.parametrize("n", [160, 7, 200])
 def test_encode_shapes(ctx, orc, n):
     torch = gu.torch_cuda()
