@@ -45,12 +45,8 @@ __device__ __forceinline__ uint32_t alaw_abs(uint32_t code)
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 ld_stream(const uint4 *p)
 {
-#ifdef IGDSP_AB_PLAIN_LOADS
-    return *p;                                                  // A/B: default cache policy
-#else
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
-#endif
 }
 
 // write-once 16-byte store (records / PCM are never re-read by this launch)
@@ -314,12 +310,7 @@ __device__ __forceinline__ uint2 lut_at(const uint2 *lut, uint32_t t, uint32_t o
 {
     // byte address = off | (byte_k(t) << 8); v_perm_b32: sel bytes 4..7 pick from t, 0..3 from off, 0x0C = 0x00
     const uint32_t addr = __builtin_amdgcn_perm(t, off, sel);
-#ifdef IGDSP_AB_NOLUT
-    (void)lut;
-    return make_uint2(addr >> 3, addr & 0x7FFFu);             // A/B only: same VALU, no LDS read (results wrong)
-#else
     return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(lut) + addr);
-#endif
 }
 
 __device__ __forceinline__ uint32_t pack_pcm(uint32_t w, uint32_t k, uint32_t ax0, uint32_t ax1)
@@ -385,16 +376,6 @@ __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half
     // `refill` = this lane's first piece of the NEXT super-chunk's same half: piece j's register is
     // reloaded the moment piece j has been folded, so the five loads trickle out evenly and get
     // most of an iteration of lead time.
-#ifdef IGDSP_AB_NOCOMPUTE
-    // A/B only: the kernel's exact load / refill / strip / store pattern with the per-sample work removed
-#pragma unroll
-    for (int j = 0; j < kLoadsPerChunk; ++j) {
-        strip_half[j * 64 + lane] = make_uint2(d[j].x ^ d[j].y, (d[j].z ^ d[j].w) & 0x7FFFFFFFu);
-        d[j] = ld_stream(refill + j * 64);
-    }
-    (void)lut; (void)lm; (void)pm; (void)off; (void)pcm_half;
-    return;
-#endif
     uint2 e[2][8];
     uint32_t wa[2], wb[2];
     auto issue = [&](int u) {
@@ -419,22 +400,14 @@ __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half
         bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
         sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
         sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
-#ifndef IGDSP_AB_NOMAX
         peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
         peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
-#else
-        peak |= e[k][0].y;   // diagnostic build only: drops 3 of 4 max3 per unit (results wrong)
-#endif
         if (STORE_PCM) {
             o[4 * k + 0] = pack_pcm(wa[k], 0, e[k][0].y, e[k][1].y); o[4 * k + 1] = pack_pcm(wa[k], 2, e[k][2].y, e[k][3].y);
             o[4 * k + 2] = pack_pcm(wb[k], 0, e[k][4].y, e[k][5].y); o[4 * k + 3] = pack_pcm(wb[k], 2, e[k][6].y, e[k][7].y);
         }
         if (k == 1) {                           // piece j complete
-#ifndef IGDSP_AB_NOPROBE
             strip_half[j * 64 + lane] = make_uint2(sum, peak | (bsum << 16) | probe_fail(d[j], pm[j]));
-#else
-            strip_half[j * 64 + lane] = make_uint2(sum, peak | (bsum << 16));   // diagnostic build only
-#endif
             if (STORE_PCM) {
                 // Each lane holds 32 contiguous PCM bytes (A = o[0..3], B = o[4..7]); four neighbouring lanes hold
                 // 128.  A quad-local DPP shuffle regroups them so that one store instruction writes 64 contiguous
@@ -595,9 +568,6 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
             if (DIAG) d_d = now_cycles();
             const uint32_t s_after = has_next ? grab() : 0xFFFFFFFFu;   // its LDS round trip hides under the frame fold below
 
-#ifdef IGDSP_AB_PRIO
-            __builtin_amdgcn_s_setprio(IGDSP_AB_PRIO);
-#endif
             wave_lds_fence();
             {
                 const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kPiecesPerFrame);   // 80 B rows, 16 B aligned
@@ -612,23 +582,13 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
                     fail |= v.y | v.w;
                 }
                 uint32_t bm, fl;
-#ifndef IGDSP_AB_NOSTORE
                 st_stream(reinterpret_cast<uint4 *>(stats + (f0 + lane)), pack_stats160(s, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl));
-#else
-                {   // diagnostic build only: keep the math alive, store one record per launch
-                    const uint4 r = pack_stats160(s, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl);
-                    if (r.x == 0x12345678u && r.y == 0x9ABCDEF0u) st_stream(reinterpret_cast<uint4 *>(stats + (f0 + lane)), r);
-                }
-#endif
                 if (AGG) {
                     a_sumsq += s << 4; a_frames += 1u; a_sil += (fl & IGDSP_FLAG_SILENT) ? 1u : 0u;
                     a_clip += (fl & IGDSP_FLAG_CLIPPED) ? 1u : 0u; a_bm += bm; a_peak = max(a_peak, peak);
                 }
             }
             wave_lds_fence();
-#ifdef IGDSP_AB_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
             if (DIAG) { d_iter += 1; d_setup += d_b - d_a; d_px += d_c - d_b; d_py += d_d - d_c; d_red += now_cycles() - d_d; }
             if (!has_next) break;
             sidx = s_next;

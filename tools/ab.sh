@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B: rebuild with -D flags on the box and bench each; usage: tools/ab.sh "<flags A>" "<flags B>" ...  (bench args via BENCH_ARGS)
+# A/B: rebuild with -D flags on the box and bench each (the diagnostic IGDSP_AB_* knobs — builds whose RESULTS ARE WRONG —
+# live in tools/ab_knobs.patch: `git apply tools/ab_knobs.patch` first, `git apply -R` after); usage: tools/ab.sh "<flags A>" "<flags B>" ...  (bench args via BENCH_ARGS)
 for fl in "$@"; do
   IGDSP_CXXFLAGS="$fl" python3 -m igate4xsoftphonedsp_amd.build --force > /dev/null 2>&1 || { echo "build failed: $fl"; continue; }
   for i in 1 2; do
