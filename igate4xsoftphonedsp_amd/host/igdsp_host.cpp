@@ -3,6 +3,9 @@
 #include "igdsp_host.h"
 
 #include <arpa/inet.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -302,6 +305,35 @@ int igdsp_host_get_trx(void *h, int slot, trx *out)
 
 igdsp_ctx *igdsp_host_ctx(void *h) { return h ? static_cast<RoIP_ED137 *>(h)->ctx() : nullptr; }
 uint32_t igdsp_host_ed137_events(void *h) { return h ? static_cast<RoIP_ED137 *>(h)->ed137Events : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// FIFO producer for the reference's AudioMeter consumer (audiometer.cpp:11-34)
+int igdsp_meter_fifo_open(const char *card, int timeout_ms)
+{
+    if (!card) return IGDSP_EINVAL;
+    char path[256];
+    if (std::snprintf(path, sizeof path, "/tmp/capturefifo%s", card) >= (int)sizeof path) return IGDSP_EINVAL;
+    for (int waited = 0;; ++waited) {
+        const int fd = ::open(path, O_WRONLY | O_NONBLOCK);          // fails with ENXIO until the reader has opened it
+        if (fd >= 0) {
+            ::fcntl(fd, F_SETFL, ::fcntl(fd, F_GETFL) & ~O_NONBLOCK);
+            return fd;
+        }
+        if (waited >= timeout_ms) return IGDSP_ENOENT;
+        ::usleep(1000);
+    }
+}
+
+int igdsp_meter_fifo_write(int fd, int level)
+{
+    if (fd < 0) return IGDSP_EINVAL;
+    char rec[32];                                                   // one record per read(in_fd, in, 32), NUL padded
+    std::memset(rec, 0, sizeof rec);
+    std::snprintf(rec, sizeof rec, "%d", level);
+    return ::write(fd, rec, sizeof rec) == (ssize_t)sizeof rec ? IGDSP_OK : IGDSP_EDEVICE;
+}
+
+int igdsp_meter_fifo_close(int fd) { return (fd >= 0 && ::close(fd) == 0) ? IGDSP_OK : IGDSP_EINVAL; }
 
 // ---------------------------------------------------------------------------------------------
 // Recorder with the reference's writeRTPWav signature and byte-for-byte the same file:

@@ -139,6 +139,13 @@ igdsp_ctx  *igdsp_host_ctx(void *h);
 int         igdsp_host_keeplog(void *h, int slot, double audioInLevel);
 int         igdsp_host_ptt_event(void *h, int slot, const char *strEvent, const char *url, double audioInLevel, char *json, size_t cap);
 int         igdsp_host_get_window(void *h, int slot, ptt_window *out);
+// Meter output on the reference's other channel: AudioMeter (audiometer.cpp:11-34) reads ASCII decimal levels from the
+// FIFO /tmp/capturefifo<card>, 32 bytes per read, and emits onValueChanged(int(float(v*100.0/30000.0))).  These write
+// such records, so the reference's own meter consumer can be fed from igdsp_poll().rms.  open() waits up to
+// `timeout_ms` for a reader (the reference creates the FIFO itself); returns an fd or a negative IGDSP_E*.
+int igdsp_meter_fifo_open(const char *card, int timeout_ms);
+int igdsp_meter_fifo_write(int fd, int level);
+int igdsp_meter_fifo_close(int fd);
 // WavWriter-compatible recorder (WavWriter.cpp:41-156): writeRTPWav signature, same bytes on disk
 void *igdsp_wav_start(const char *path, int rate);
 int   igdsp_wav_writeRTPWav(void *w, const char *pktbuf, const char *payloadbuf, unsigned pktlen, unsigned payloadlen);

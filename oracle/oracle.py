@@ -52,7 +52,14 @@ def build(force: bool = False) -> str:
         os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "igdsp_oracle.c"))
     ):
         subprocess.run(["make", "-C", _HERE, "-s", "_build/libigdsp_oracle.so"], check=True)
-    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF_WAV_PATH) or not os.path.exists(_REF_METER_PATH)):
+    def _ref_stale():
+        outs = [_REF_WAV_PATH, _REF_METER_PATH]
+        if not all(os.path.exists(o) for o in outs):
+            return True
+        newest_src = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ref_wavwriter_shim.cpp", "ref_audiometer_shim.cpp", "Makefile"))
+        return min(os.path.getmtime(o) for o in outs) < newest_src
+
+    if os.path.isdir("/root/reference") and (force or _ref_stale()):
         subprocess.run(["make", "-C", _HERE, "-s", "ref"], check=True)
     return _LIB_PATH
 

@@ -47,3 +47,17 @@ extern "C" int ref_audiometer_percent(const char *card, const int *levels, int n
     for (int i = 0; i < m; ++i) percent_out[i] = got[i];
     return (int)got.size();
 }
+
+// Consumer only: run the REAL AudioMeter::getAudioLevel() on /tmp/capturefifo<card> until the (external)
+// writer closes the FIFO; returns how many values it emitted.  Used to check that the PRODUCT's FIFO writer
+// (igdsp_meter_fifo_*, host library) drives the reference's own meter code.
+extern "C" int ref_audiometer_consume(const char *card, int max_out, int *percent_out)
+{
+    AudioMeter meter(QString::fromLatin1(card));
+    std::vector<int> got;
+    QObject::connect(&meter, &AudioMeter::onValueChanged, [&got](int v) { got.push_back(v); });
+    meter.getAudioLevel();
+    const int m = (int)got.size() < max_out ? (int)got.size() : max_out;
+    for (int i = 0; i < m; ++i) percent_out[i] = got[i];
+    return (int)got.size();
+}

@@ -57,6 +57,9 @@ def load():
         L.igdsp_host_get_window.restype = C.c_int; L.igdsp_host_get_window.argtypes = [C.c_void_p, C.c_int, C.POINTER(PttWindow)]
         L.transport_rtp_cb.restype = None; L.transport_rtp_cb.argtypes = [C.POINTER(TpAdapter), C.c_void_p, C.c_long]
         L.transport_send_rtp.restype = C.c_int; L.transport_send_rtp.argtypes = [C.POINTER(TpAdapter), C.c_void_p, C.c_size_t]
+        L.igdsp_meter_fifo_open.restype = C.c_int; L.igdsp_meter_fifo_open.argtypes = [C.c_char_p, C.c_int]
+        L.igdsp_meter_fifo_write.restype = C.c_int; L.igdsp_meter_fifo_write.argtypes = [C.c_int, C.c_int]
+        L.igdsp_meter_fifo_close.restype = C.c_int; L.igdsp_meter_fifo_close.argtypes = [C.c_int]
         L.igdsp_wav_start.restype = C.c_void_p; L.igdsp_wav_start.argtypes = [C.c_char_p, C.c_int]
         L.igdsp_wav_writeRTPWav.restype = C.c_int
         L.igdsp_wav_writeRTPWav.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]

@@ -93,3 +93,40 @@ def test_transport_rtp_cb_fuzz_against_depayload_oracle(orc):
     assert L.transport_send_rtp(adapters[0], sil, 300) == -22 and L.transport_send_rtp(adapters[0], sil, 5) == -22
     for a in adapters.values():
         L.igdsp_host_adapter_free(a)
+
+
+def test_fifo_writer_drives_the_real_reference_audiometer(orc):
+    """The product's FIFO producer (igdsp_meter_fifo_*) feeding the REAL reference AudioMeter::getAudioLevel()
+    (oracle/_ref, built from audiometer.cpp + moc): the reference's own consumer code emits exactly
+    int(float(v*100.0/30000.0)) for every level we write."""
+    import ctypes as C
+    import threading
+    import time
+
+    import pytest
+
+    if not orc.ref_audiometer_available():
+        pytest.skip("oracle/_ref/libref_audiometer.so not built (reference / Qt not present)")
+    L = hu.load()
+    R = C.CDLL(os.path.join(os.path.dirname(orc.__file__), "_ref", "libref_audiometer.so"))
+    R.ref_audiometer_consume.restype = C.c_int
+    card = f"igdspw{os.getpid()}".encode()
+    levels = [0, 150, 300, 10138, 29999, 30000, 32124, 32256]
+    assert L.igdsp_meter_fifo_open(b"nobody-listens", 5) == -2          # no reader: IGDSP_ENOENT after the timeout
+
+    def produce():
+        fd = L.igdsp_meter_fifo_open(card, 5000)
+        assert fd >= 0
+        for v in levels:
+            assert L.igdsp_meter_fifo_write(fd, v) == 0
+            time.sleep(0.002)
+        assert L.igdsp_meter_fifo_close(fd) == 0
+
+    t = threading.Thread(target=produce)
+    t.start()
+    out = (C.c_int * 64)()
+    n = R.ref_audiometer_consume(card, 64, out)
+    t.join()
+    os.unlink(f"/tmp/capturefifo{card.decode()}")
+    assert n == len(levels)
+    assert list(out[:n]) == [orc.percent(v) for v in levels]
