@@ -1349,14 +1349,27 @@ __global__ __launch_bounds__(256) void k_depayload16(const uint8_t *__restrict__
         if (h.len > b0) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(pkt + hdr + b0);
             const uint32_t nb = min(h.len - b0, 16u);
+            if (hdr + b0 + 16u <= stride) {
+                // whole piece inside the slot: ONE 16-byte load at dword alignment (gfx950 global loads need only
+                // dword alignment for dwordx4) instead of four dword loads, then mask what lies past the length
+                struct __attribute__((packed, aligned(4))) Q { uint32_t a, b, c, d; };
+                const Q qv = *reinterpret_cast<const Q *>(src);
+                const uint32_t x[4] = {qv.a, qv.b, qv.c, qv.d};
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k)
-                if (nb > 4u * k) {                                  // the dword may extend past the packet's size but never past its slot
-                    uint32_t x = (hdr + b0 + 4u * k + 4u <= stride) ? src[k] : 0u;
-                    const uint32_t keep = nb - 4u * k;
-                    if (keep < 4u) x &= (1u << (8u * keep)) - 1u;
-                    v[k] = x;
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const uint32_t keep = nb > 4u * k ? min(nb - 4u * k, 4u) : 0u;
+                    v[k] = keep == 4u ? x[k] : (keep == 0u ? 0u : (x[k] & ((1u << (8u * keep)) - 1u)));
                 }
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k)
+                    if (nb > 4u * k) {                              // the dword may extend past the packet's size but never past its slot
+                        uint32_t x = (hdr + b0 + 4u * k + 4u <= stride) ? src[k] : 0u;
+                        const uint32_t keep = nb - 4u * k;
+                        if (keep < 4u) x &= (1u << (8u * keep)) - 1u;
+                        v[k] = x;
+                    }
+            }
         }
         reinterpret_cast<uint4 *>(payload)[p] = make_uint4(v[0], v[1], v[2], v[3]);
     }
