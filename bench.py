@@ -34,6 +34,7 @@ BYTES_PER_SAMPLE = {"meter": (160 + 1 + 16) / 160.0, "store": (160 + 1 + 16 + 32
                     "roundtrip": (160 + 1 + 16 + 160) / 160.0,   # config #5: read 1 + write 1 + record
                     "depayload": (180 + 160 + 2 + 8) / 160.0,
                     "rtp": (192 + 1 + 16 + 8) / 160.0,           # fused: 192 B packet slot in, record + info out
+                    "packets": (180 + 1 + 16 + 8) / 160.0,       # fused, packets packed at their natural 180 B stride
                     "encode": (320 + 1 + 160) / 160.0}           # a2: int16 in, code out    # 8(f) rank 1: 180 B packet in, dense payload + len + info out
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
@@ -45,7 +46,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels", type=int, default=65536, help="channels PER GPU")
     ap.add_argument("--frames", type=int, default=128)
-    ap.add_argument("--mode", choices=["meter", "store", "roundtrip", "depayload", "rtp", "encode"], default="meter")
+    ap.add_argument("--mode", choices=["meter", "store", "roundtrip", "depayload", "rtp", "packets", "encode"], default="meter")
     ap.add_argument("--variant", type=int, default=0, help="0 tuned default, 1 wave-per-frame, 2 chunk32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -153,6 +154,12 @@ def main():
         d_slots[:, :, 12] = 0x90
         d_slots[:, :, 13] = 0
         d_info = torch.empty((F_ * C_,), dtype=torch.int64, device="cuda")
+    if args.mode == "packets":                                            # [F][C][180] ED-137 packets, PT 0, all full
+        d_slots = torch.empty((F_, C_, 180), dtype=torch.uint8, device="cuda")
+        ctx.gen_uniform(d_slots, d_slots.numel(), seed=7, stream=hs)
+        d_slots[:, :, 0] = 0x90
+        d_slots[:, :, 1] = 0
+        d_info = torch.empty((F_ * C_,), dtype=torch.int64, device="cuda")
     if args.mode == "roundtrip":                                          # BASELINE configs[4]: mixed A-law / mu-law, D-speech
         d_cd[1::2] = 8
         # D-speech: two-tone + noise, amplitude 1000*(1 + c mod 30), encoded with the oracle's encoder.
@@ -185,6 +192,8 @@ def main():
             ctx.encode(d_pcm_in, d_cd, C_, F_, n, d_out, stream=hs)
         elif args.mode == "rtp":
             ctx.decode_meter_rtp(d_slots, d_cd, C_, F_, d_st, info=d_info, agg=aggs[b], rank=rank, stream=hs)
+        elif args.mode == "packets":
+            ctx.decode_meter_packets(d_slots, None, d_cd, C_, F_, 180, 20, d_st, info=d_info, agg=aggs[b], rank=rank, stream=hs)
         elif args.mode == "depayload":
             ctx.depayload(d_pk, None, d_radio, C_, F_, 180, n, d_pl, d_len, d_info, stream=hs)
         elif args.mode == "roundtrip":
@@ -238,7 +247,7 @@ def main():
     value = total_samples / dt / 1e6
     bps = BYTES_PER_SAMPLE[args.mode]
     achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9
-    kernel_name = "k_encode_v8" if args.mode == "encode" else "k_meter_rtp64" if args.mode == "rtp" else "k_depayload16" if args.mode == "depayload" else "k_roundtrip_chunk64" if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64")
+    kernel_name = "k_encode_v8" if args.mode == "encode" else "k_meter_rtp64" if args.mode in ("rtp", "packets") else "k_depayload16" if args.mode == "depayload" else "k_roundtrip_chunk64" if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64")
 
     out = {
         "metric": "Msamples/s G.711 decode+RMS, 65536ch@8kHz; %HBM roofline at 1/2/4/8 GPU",

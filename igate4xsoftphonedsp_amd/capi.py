@@ -82,6 +82,7 @@ PROTOTYPES = [
     ("igdsp_agg_reset", _int, [_vp, _vp, _vp]),
     ("igdsp_depayload", _int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     ("igdsp_decode_meter_rtp", _int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
+    ("igdsp_decode_meter_packets", _int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
     ("igdsp_g726_reorder", _int, [_vp, _vp, _vp, _u64, _int, _vp]),
     ("igdsp_gen_uniform", _int, [_vp, _vp, _u64, _u64, _u64, _vp]),
     ("igdsp_dev_alloc", _int, [_vp, C.POINTER(_vp), C.c_size_t]),
@@ -243,6 +244,10 @@ class Context:
     def decode_meter_rtp(self, slots, codec, C_, F_, stats, info=None, agg=None, rank=0, stream=None):
         self._ck(self.L.igdsp_decode_meter_rtp(self.h, _ptr(slots), _ptr(codec), C_, F_, _ptr(stats), _ptr(info), _ptr(agg), rank, stream),
                  "igdsp_decode_meter_rtp")
+
+    def decode_meter_packets(self, packets, sizes, codec, C_, F_, stride, hdr, stats, info=None, agg=None, rank=0, stream=None):
+        self._ck(self.L.igdsp_decode_meter_packets(self.h, _ptr(packets), _ptr(sizes), _ptr(codec), C_, F_, stride, hdr, _ptr(stats),
+                                                   _ptr(info), _ptr(agg), rank, stream), "igdsp_decode_meter_packets")
 
     def g726_reorder(self, d_in, d_out, n_bytes, mode, stream=None):
         self._ck(self.L.igdsp_g726_reorder(self.h, _ptr(d_in), _ptr(d_out), n_bytes, mode, stream), "igdsp_g726_reorder")

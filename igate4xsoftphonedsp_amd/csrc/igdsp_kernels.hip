@@ -729,10 +729,21 @@ constexpr int kRtpHalfLoads = kSlotPieces * kChunkFrames / 64;     // 6 loads pe
 constexpr int kRtpStrip = kSuperFrames * kSlotPieces;              // 768 entries = 6 KiB per wave
 constexpr int kRtpWaves = 12;                                      // 64 KiB LUT + 72 KiB strips
 
+// 16 bytes at dword (not 16-byte) alignment: gfx950 global loads only need dword alignment for dwordx4
+__device__ __forceinline__ uint4 ld16_dw(const uint8_t *p)
+{
+    struct __attribute__((packed, aligned(4))) Q { uint32_t a, b, c, d; };
+    const Q q = *reinterpret_cast<const Q *>(p);
+    return make_uint4(q.a, q.b, q.c, q.d);
+}
+
+// SLOT = true : 192-byte slots (size word + pad + packet at +12), every piece 16-byte aligned.
+// SLOT = false: packets packed at `stride` bytes exactly as received; piece addresses are only dword aligned.
+template <bool SLOT>
 __device__ __forceinline__ void rtp_half(const uint2 *lut, uint2 *strip_half, uint4 (&d)[kRtpHalfLoads],
                                          const uint32_t (&lm)[kRtpHalfLoads], const uint32_t (&pm)[kRtpHalfLoads],
                                          const uint32_t (&hs)[kRtpHalfLoads], const uint32_t off, const uint32_t lane,
-                                         const uint4 *refill)
+                                         const uint8_t *refill_base, const uint32_t (&roff)[kRtpHalfLoads])
 {
     uint2 e[2][8];
     uint32_t wa[2], wb[2];
@@ -761,20 +772,23 @@ __device__ __forceinline__ void rtp_half(const uint2 *lut, uint2 *strip_half, ui
         peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
         if (k == 1) {
             uint2 ent = make_uint2(sum, peak | (bsum << 16) | probe_fail(d[j], pm[j]));
-            // header pieces: piece 0 -> {size word, RTP bytes 0-3}; piece 1 -> {ext profile/length, ED-137 word}
-            if (hs[j] == 1u) ent = make_uint2(d[j].x, d[j].w);
+            // header pieces.  SLOT: piece 0 = slot bytes 0..15 -> {size word, RTP bytes 0-3}; piece 1 = bytes 16..31.
+            //                packed: piece 0 = packet bytes 0..15 -> {RTP bytes 0-3, -};      piece 1 = bytes 4..19.
+            // either way piece 1 ends with {extension profile/length, ED-137 word}
+            if (hs[j] == 1u) ent = SLOT ? make_uint2(d[j].x, d[j].w) : make_uint2(0u, d[j].x);
             if (hs[j] == 2u) ent = make_uint2(d[j].z, d[j].w);
             strip_half[j * 64 + lane] = ent;
-            d[j] = ld_stream(refill + j * 64);
+            d[j] = SLOT ? ld_stream(reinterpret_cast<const uint4 *>(refill_base + roff[j])) : ld16_dw(refill_base + roff[j]);
             sum = 0; peak = 0; bsum = 0;
         }
     }
 }
 
-template <bool AGG>
+template <bool AGG, bool SLOT>
 __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
-    const uint8_t *__restrict__ slots, const uint8_t *__restrict__ codec, uint32_t C, uint32_t n_frames,
-    igdsp_frame_stats *__restrict__ stats, igdsp_rtp_info *__restrict__ info, igdsp_aggregate *agg, uint32_t rank)
+    const uint8_t *__restrict__ slots, const uint16_t *__restrict__ sizes, const uint8_t *__restrict__ codec, uint32_t C,
+    uint32_t n_frames, uint32_t stride, uint32_t hdr, igdsp_frame_stats *__restrict__ stats, igdsp_rtp_info *__restrict__ info,
+    igdsp_aggregate *agg, uint32_t rank)
 {
     __shared__ uint2 lds[kLutEntries + kRtpWaves * kRtpStrip];
     __shared__ uint32_t next_item;
@@ -785,7 +799,8 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint2 *strip = lds + kLutEntries + wave * kRtpStrip;
     const uint32_t off = (lane & 31u) * 8u;
-    uint32_t fr[kRtpHalfLoads], pm[kRtpHalfLoads], hs[kRtpHalfLoads];
+    uint32_t pm[kRtpHalfLoads], hs[kRtpHalfLoads], fr[kRtpHalfLoads];
+    uint32_t roff0[kRtpHalfLoads], roff1[kRtpHalfLoads];       // byte offset of this lane's pieces inside a super-chunk
 #pragma unroll
     for (int j = 0; j < kRtpHalfLoads; ++j) {
         const uint32_t p = (uint32_t)j * 64u + lane;
@@ -793,18 +808,24 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
         const uint32_t q = p - fr[j] * 12u;               // piece within the slot: 0, 1 header; 2..11 payload
         hs[j] = q < 2u ? q + 1u : 0u;
         pm[j] = q < 2u ? 0u : probe_mask(q - 2u);
+        if (SLOT) {
+            roff0[j] = p * 16u;
+            roff1[j] = (p + (uint32_t)(kRtpStrip / 2)) * 16u;
+        } else {
+            const uint32_t po = q == 0u ? 0u : (q == 1u ? 4u : hdr + 16u * (q - 2u));
+            roff0[j] = fr[j] * stride + po;
+            roff1[j] = (fr[j] + (uint32_t)kChunkFrames) * stride + po;
+        }
     }
     const uint32_t G = gridDim.x;
     const uint32_t n_super = n_frames / kSuperFrames;
-    const uint4 *src16 = reinterpret_cast<const uint4 *>(slots);
+    const uint64_t super_bytes = (uint64_t)kSuperFrames * (SLOT ? (uint32_t)IGDSP_SLOT_BYTES : stride);
+    const uint32_t full = SLOT ? 180u : hdr + (uint32_t)kFrame;
+    const uint32_t hbytes = SLOT ? 20u : hdr;
     uint64_t a_sumsq = 0;
     uint32_t a_frames = 0, a_sil = 0, a_clip = 0, a_bm = 0, a_peak = 0;
 
-    auto fetch_half = [&](uint4 (&dst)[kRtpHalfLoads], uint32_t sidx, uint32_t half) {
-        const uint32_t p0 = sidx * (uint32_t)kRtpStrip + half * (uint32_t)(kRtpStrip / 2) + lane;
-#pragma unroll
-        for (int j = 0; j < kRtpHalfLoads; ++j) dst[j] = ld_stream(src16 + (p0 + (uint32_t)j * 64u));
-    };
+    auto ld = [&](const uint8_t *b, uint32_t o) { return SLOT ? ld_stream(reinterpret_cast<const uint4 *>(b + o)) : ld16_dw(b + o); };
     auto fetch_pt = [&](uint32_t sidx) { return (uint32_t)codec[(sidx * (uint32_t)kSuperFrames + lane) % C]; };
     auto grab = [&]() {
         uint32_t k = 0;
@@ -816,8 +837,13 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     if (sidx < n_super) {
         uint4 X[kRtpHalfLoads], Y[kRtpHalfLoads];
         uint32_t cur_pt = fetch_pt(sidx);
-        fetch_half(X, sidx, 0);
-        fetch_half(Y, sidx, 1);
+        {
+            const uint8_t *b0 = slots + (uint64_t)sidx * super_bytes;
+#pragma unroll
+            for (int j = 0; j < kRtpHalfLoads; ++j) X[j] = ld(b0, roff0[j]);
+#pragma unroll
+            for (int j = 0; j < kRtpHalfLoads; ++j) Y[j] = ld(b0, roff1[j]);
+        }
         uint32_t k_next = grab();
         for (;;) {
             const uint32_t s_next = blockIdx.x + k_next * G;
@@ -833,15 +859,17 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
                 lm0[j] = (uint32_t)__builtin_amdgcn_sbfe(am_lo, fr[j], 1) & 0x80808080u;
                 lm1[j] = (uint32_t)__builtin_amdgcn_sbfe(am_hi, fr[j], 1) & 0x80808080u;
             }
-            const uint4 *nsrc = src16 + (s_load * (uint32_t)kRtpStrip + lane);
+            const uint8_t *nbase = slots + (uint64_t)s_load * super_bytes;
             const uint32_t nxt_pt = fetch_pt(s_load);
-            rtp_half(lds, strip, X, lm0, pm, hs, off, lane, nsrc);
-            rtp_half(lds, strip + kRtpStrip / 2, Y, lm1, pm, hs, off, lane, nsrc + kRtpStrip / 2);
+            uint32_t my_size = full;
+            if (!SLOT && sizes != nullptr) my_size = sizes[f0 + lane];
+            rtp_half<SLOT>(lds, strip, X, lm0, pm, hs, off, lane, nbase, roff0);
+            rtp_half<SLOT>(lds, strip + kRtpStrip / 2, Y, lm1, pm, hs, off, lane, nbase, roff1);
             if (has_next) k_next = grab();
             wave_lds_fence();
             {
                 const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kSlotPieces);   // 96-byte rows
-                const uint4 h = row[0];                   // {size word, RTP bytes 0-3, ext profile/length, ED-137 word}
+                const uint4 h = row[0];                   // {size word | 0, RTP bytes 0-3, ext profile/length, ED-137 word}
                 uint64_t s = 0;
                 uint32_t peak = 0, bsum = 0, fail = 0;
 #pragma unroll
@@ -852,26 +880,28 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
                     bsum += ((v.y >> 16) & 0x7FFFu) + ((v.w >> 16) & 0x7FFFu);
                     fail |= v.y | v.w;
                 }
-                // header: same rules as parse_rtp() on a radio call
-                const uint32_t size = h.x & 0xFFFFu, w0 = h.y, pt = (w0 >> 8) & 0x7Fu;
+                // header: same rules as parse_rtp()
+                const uint32_t size = SLOT ? (h.x & 0xFFFFu) : my_size, w0 = h.y, pt = (w0 >> 8) & 0x7Fu;
                 uint32_t hf = (((w0 >> 6) & 3u) == 2u ? IGDSP_RTP_V2 : 0u) | ((w0 & 0x10u) ? IGDSP_RTP_X : 0u) |
                               ((w0 & 0x8000u) ? IGDSP_RTP_MARKER : 0u);
                 uint32_t ed = 0, plen = 0;
-                if (size < 20u) hf = IGDSP_RTP_RUNT;
+                if (size < hbytes) hf = IGDSP_RTP_RUNT;
                 else {
-                    plen = size - 20u;
-                    if (pt == 8u || pt == 0u || pt == 18u || pt == 123u) ed = __builtin_bswap32(h.w);
-                    if ((w0 & 0x10u) && h.z == 0x01006701u) hf |= IGDSP_RTP_ED137_OK;
+                    plen = size - hbytes;
+                    if (hbytes == 20u) {
+                        if (pt == 8u || pt == 0u || pt == 18u || pt == 123u) ed = __builtin_bswap32(h.w);
+                        if ((w0 & 0x10u) && h.z == 0x01006701u) hf |= IGDSP_RTP_ED137_OK;
+                    }
                     if (pt == 123u) hf |= IGDSP_RTP_KEEPALIVE;
                     if (plen > (uint32_t)kFrame) hf |= IGDSP_RTP_OVERSIZE;
                     else if ((pt == 0u || pt == 8u) && plen > 0u) hf |= IGDSP_RTP_METERED;
                 }
-                const bool metered = size == 180u && pt == cur_pt && (pt == 0u || pt == 8u);
+                const bool metered = size == full && pt == cur_pt && (pt == 0u || pt == 8u);
                 const uint32_t fi = f0 + lane;
                 if (info != nullptr) {
                     uint2 rec;
                     rec.x = ed;
-                    rec.y = (size < 20u ? 0u : plen) | (((size >= 2u + 12u - 12u) ? pt : 0u) << 16) | (hf << 24);
+                    rec.y = (size < hbytes ? 0u : plen) | ((size >= 2u ? pt : 0u) << 16) | (hf << 24);
                     *reinterpret_cast<uint2 *>(info + fi) = rec;
                 }
                 uint32_t bm = 0, fl = 0;
@@ -1634,15 +1664,22 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
     return hipGetLastError();
 }
 
-hipError_t launch_decode_meter_rtp(const LaunchCfg &cfg, const uint8_t *slots, const uint8_t *codec, uint32_t C, uint32_t F,
-                                   igdsp_frame_stats *stats, igdsp_rtp_info *info, igdsp_aggregate *agg, uint32_t rank,
-                                   hipStream_t s)
+hipError_t launch_decode_meter_rtp(const LaunchCfg &cfg, const uint8_t *slots, const uint16_t *sizes, const uint8_t *codec, uint32_t C,
+                                   uint32_t F, uint32_t stride, uint32_t hdr, igdsp_frame_stats *stats, igdsp_rtp_info *info,
+                                   igdsp_aggregate *agg, uint32_t rank, hipStream_t s)
 {
+    // stride == 0: the 192-byte slot format; otherwise packets packed at `stride` with a `hdr`-byte RTP header
     const uint32_t n_frames = C * F;                       // caller guarantees a multiple of 64
     if (n_frames == 0) return hipSuccess;
     const uint32_t grid = blocks_for(n_frames / kSuperFrames, kRtpWaves, (uint32_t)cfg.compute_units);
-    if (agg) hipLaunchKernelGGL((k_meter_rtp64<true>), dim3(grid), dim3(kRtpWaves * 64), 0, s, slots, codec, C, n_frames, stats, info, agg, rank);
-    else     hipLaunchKernelGGL((k_meter_rtp64<false>), dim3(grid), dim3(kRtpWaves * 64), 0, s, slots, codec, C, n_frames, stats, info, agg, rank);
+    const dim3 blk(kRtpWaves * 64);
+    if (stride == 0) {
+        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank);
+        else     hipLaunchKernelGGL((k_meter_rtp64<false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank);
+    } else {
+        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank);
+        else     hipLaunchKernelGGL((k_meter_rtp64<false, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank);
+    }
     return hipGetLastError();
 }
 

@@ -280,6 +280,15 @@ int igdsp_decode_meter_rtp(igdsp_ctx *ctx, const uint8_t *d_slots, const uint8_t
                            igdsp_frame_stats *d_stats, igdsp_rtp_info *d_info,
                            igdsp_aggregate *d_agg, uint32_t rank, void *stream);
 
+/* The same fused kernel over packets packed exactly as igdsp_depayload takes them: packets[f][c][pkt_stride]
+ * (pkt_stride % 4 == 0, >= hdr_bytes + 160), sizes[f][c] (NULL: every packet is hdr_bytes + 160 long), ONE header
+ * type per launch (hdr_bytes = 20 for ED-137 radio legs, 12 for plain SIP legs).  Piece addresses are only dword
+ * aligned here; gfx950 global loads need no more.  Metered iff size == hdr_bytes + 160 and PT == codec[c]. */
+int igdsp_decode_meter_packets(igdsp_ctx *ctx, const uint8_t *d_packets, const uint16_t *d_sizes, const uint8_t *d_codec,
+                               uint32_t n_channels, uint32_t n_frames, uint32_t pkt_stride, uint32_t hdr_bytes,
+                               igdsp_frame_stats *d_stats, igdsp_rtp_info *d_info,
+                               igdsp_aggregate *d_agg, uint32_t rank, void *stream);
+
 /* ---- G.726 code-word reorder (RoIP_ED137::changeUplinkOrder, roip_ed137.cpp:6379-6499) ----
  * Repacks G.726 code words between the RFC 3551 and AAL2 bit orders, bug-for-bug as the reference
  * does it on its (unsigned-char) target:

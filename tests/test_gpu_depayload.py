@@ -193,3 +193,66 @@ def test_fused_rtp_slots_meter(ctx, orc, C_, F_):
     assert int(agg["peak_slot"][2]) == int(est["peak"][metered].max())
     # shape / alignment rules are reported, not silently re-routed
     assert ctx.L.igdsp_decode_meter_rtp(ctx.h, d_st.data_ptr(), d_st.data_ptr(), 33, 1, d_st.data_ptr(), None, None, 0, None) == -22
+
+
+@pytest.mark.parametrize("hdr,stride,C_,F_,with_sizes", [(20, 180, 64, 3, True), (20, 184, 96, 2, True), (12, 172, 64, 2, True),
+                                                         (12, 180, 32, 4, True), (20, 256, 128, 3, True), (20, 180, 64, 2, False)])
+def test_fused_packed_packets_meter(ctx, orc, hdr, stride, C_, F_, with_sizes):
+    """igdsp_decode_meter_packets: the same fused kernel over packets packed at their natural stride (dword-aligned
+    loads), one header type per launch.  Same oracle relations as the slot form."""
+    torch = gu.torch_cuda()
+    n = 160
+    radio = np.full((C_,), 1 if hdr == 20 else 0, np.uint8)
+    rng = np.random.default_rng(hdr * 1000 + stride + C_)
+    codec = np.where(np.arange(C_) % 3 == 0, 8, 0).astype(np.uint8)
+    pk = orc.gen_uniform(F_ * C_ * stride, seed=stride).reshape(F_, C_, stride).copy()
+    sizes = np.zeros((F_, C_), np.uint16)
+    for f in range(F_):
+        for c in range(C_):
+            kind = int(rng.integers(0, 10)) if with_sizes else int(rng.integers(0, 6))
+            pt = int(codec[c]) if kind < 6 else [123, 18, 8 - int(codec[c]), 96][kind - 6]
+            plen = n if kind != 9 else 24
+            if kind == 6:
+                plen = 0
+            if not with_sizes and rng.integers(0, 4) == 0:
+                pt = 8 - int(codec[c])                                       # PT mismatch at full size
+            body = orc.gen_uniform(max(plen, 1), seed=f * 1000 + c).tobytes()[:plen]
+            pkt = bytearray(hu.rtp_packet(pt, f, body, hdr == 20, int(rng.integers(0, 2 ** 32))))
+            if rng.integers(0, 6) == 0:
+                pkt[1] |= 0x80
+            if hdr == 20 and rng.integers(0, 6) == 0:
+                pkt[13] = 0x66
+            pk[f, c, :len(pkt)] = np.frombuffer(bytes(pkt), np.uint8)
+            sizes[f, c] = len(pkt) if kind != 8 or f % 2 else int(rng.integers(0, hdr))
+    d_st, d_info, d_agg = gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.dev_zeros(F_ * C_ * 8, 0xEE), gu.dev_zeros(capi.AGGREGATE.itemsize)
+    ctx.decode_meter_packets(gu.to_dev(pk), gu.to_dev(sizes) if with_sizes else None, gu.to_dev(codec), C_, F_, stride, hdr,
+                             d_st, info=d_info, agg=d_agg, rank=1)
+    torch.cuda.synchronize()
+    epl, elen, einfo = orc.depayload(pk, sizes if with_sizes else None, radio, n)
+    ginfo = gu.to_host(d_info, capi.RTP_INFO, (F_, C_))
+    for fld in capi.RTP_INFO.names:
+        assert np.array_equal(ginfo[fld], einfo[fld]), fld
+    full = (sizes == hdr + n) if with_sizes else np.ones((F_, C_), bool)
+    metered = full & (einfo["pt"] == codec[None, :]) & np.isin(einfo["pt"], (0, 8))
+    assert metered.any() and (~metered).any()
+    est = orc.decode_meter(epl, codec)
+    gst = gu.to_host(d_st, capi.FRAME_STATS, (F_, C_))
+    gu.assert_stats_equal(gst[metered].reshape(1, -1), est[metered].reshape(1, -1), n=n)
+    emp = gst[~metered]
+    assert np.all(emp["flags"] == capi.FLAG_EMPTY) and np.all(emp["sumsq"] == 0) and np.all(emp["peak"] == 0)
+    agg = gu.to_host(d_agg, capi.AGGREGATE)[0]
+    assert int(agg["frames"]) == int(metered.sum())
+    assert int(agg["sumsq"]) == int(est["sumsq"][metered].sum(dtype=np.uint64))
+    assert int(agg["peak_slot"][1]) == int(est["peak"][metered].max())
+    # packed and slot forms agree record for record on 180-byte radio packets
+    if hdr == 20 and stride == 180 and with_sizes:
+        d_st2 = gu.dev_zeros(F_ * C_ * 16, 0xEE)
+        ctx.decode_meter_rtp(gu.to_dev(_to_slots(pk, sizes)), gu.to_dev(codec), C_, F_, d_st2)
+        torch.cuda.synchronize()
+        assert gu.to_host(d_st2, np.uint8).tobytes() == gu.to_host(d_st, np.uint8).tobytes()
+    # argument rules
+    L, p = ctx.L, d_st.data_ptr()
+    assert L.igdsp_decode_meter_packets(ctx.h, p, None, p, 64, 1, 180, 16, p, None, None, 0, None) == -22   # header type
+    assert L.igdsp_decode_meter_packets(ctx.h, p, None, p, 64, 1, 178, 20, p, None, None, 0, None) == -22   # stride < hdr+160
+    assert L.igdsp_decode_meter_packets(ctx.h, p, None, p, 64, 1, 182, 20, p, None, None, 0, None) == -22   # stride % 4
+    assert L.igdsp_decode_meter_packets(ctx.h, p, None, p, 33, 1, 180, 20, p, None, None, 0, None) == -22   # C*F % 64
