@@ -1121,56 +1121,100 @@ __global__ __launch_bounds__(256) void k_encode_scalar(const int16_t *__restrict
 #ifndef IGDSP_RT_WAVES
 #define IGDSP_RT_WAVES 12
 #endif
-constexpr int kRtWaves = IGDSP_RT_WAVES;   // 64 KiB LUT + 32 KiB compressor table + 12 x 5 KiB strips = 156 KiB
+constexpr int kRtWaves = IGDSP_RT_WAVES;
+// LDS map of k_roundtrip_chunk64 (158 KiB of the CU's 160 KiB), chosen so that both table addresses come out
+// of the instruction stream without adds:
+//   [  0,  32 KiB)  compressor grid table  tab[law][neg][k] = enc(neg ? -4k : 4k), one byte per cell
+//   [ 32,  62 KiB)  strips of waves 0..5
+//   [ 64, 128 KiB)  expansion LUT (as in k_meter_chunk64, entry.y additionally carries law << 16)
+//   [128, 158 KiB)  strips of waves 6..11
+// Every G.711 expander output is a multiple of 4 with |x| <= 32256, so (law, sign, |x| / 4) enumerates the
+// compressor's whole input domain on this path; the table holds the compressor (enc_uni, the same arithmetic
+// igdsp_encode runs) evaluated at exactly those PCM values.  -0 (mu-law code 0x7F) lands in cell (neg, 0),
+// which holds enc(0), as two's-complement PCM would.
+constexpr uint32_t kRtEncBytes = 32768u, kRtLutOff = 65536u, kRtStripBytes = (uint32_t)kStripEntries * 8u;
+constexpr uint32_t kRtStripA = kRtEncBytes, kRtStripB = kRtLutOff + (uint32_t)kLutEntries * 8u;
+constexpr uint32_t kRtLdsBytes = kRtStripB + (uint32_t)(kRtWaves - kRtWaves / 2) * kRtStripBytes;
+static_assert(kRtStripA + (uint32_t)(kRtWaves / 2) * kRtStripBytes <= kRtLutOff, "strips A overlap the LUT");
+static_assert(kRtLdsBytes <= 160u * 1024u, "LDS budget");
 
 template <int VARIANT>
-__device__ __forceinline__ void roundtrip_half(const uint2 *lut, uint2 *strip_half, uint4 (&d)[kLoadsPerChunk],
+__device__ __forceinline__ void fill_rt_tables(uint8_t *smem)
+{
+    const EncK ku = enc_consts<VARIANT>(false), ka = enc_consts<VARIANT>(true);
+    for (uint32_t i = threadIdx.x; i < kRtEncBytes; i += blockDim.x) {
+        const int k = (int)(i & 8191u);
+        const int v = (i & 8192u) ? -4 * k : 4 * k;
+        smem[i] = (uint8_t)enc_uni<VARIANT>(v, (i & 16384u) ? ka : ku);
+    }
+    uint2 *lut = reinterpret_cast<uint2 *>(smem + kRtLutOff);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kLutEntries; i += blockDim.x) {
+        const uint32_t e = i >> 5;                 // law<<7 | code7
+        const uint32_t ax = (e & 0x80u) ? alaw_abs(e) : ulaw_abs(e);
+        const uint32_t m = ax >> 2;
+        lut[i] = make_uint2(m * m, ax | ((e & 0x80u) << 9));       // law -> bit 16, i.e. bit 14 of (y >> 2)
+    }
+}
+
+// One half (32 frames) of a super-chunk.  Three-stage software pipeline per unit of 8 samples:
+//   expansion-LUT reads of unit u+1 in flight | unit u folded, its 8 compressor-cell reads issued | unit u-1 packed
+// `offx` = replica offset | 0x100: the 0x01 in byte 1 becomes address byte 2 (the LUT's 64 KiB base) inside the v_perm.
+template <int VARIANT>
+__device__ __forceinline__ void roundtrip_half(const uint8_t *smem, uint2 *strip_half, uint4 (&d)[kLoadsPerChunk],
                                                const uint32_t (&lm)[kLoadsPerChunk], const uint32_t (&pm)[kLoadsPerChunk],
-                                               const uint32_t off, const uint32_t lane, uint4 *out_half, const uint4 *refill,
-                                               const bool do_refill, const uint8_t *enc_tab)
+                                               const uint32_t offx, const uint32_t lane, uint4 *out_half, const uint4 *refill)
 {
     uint2 e[2][8];
-    uint32_t wa[2], wb[2];
+    uint32_t wa[2], wb[2], eb[2][8];
+    auto lut = [&](uint32_t t, uint32_t sel) {
+        return *reinterpret_cast<const uint2 *>(smem + __builtin_amdgcn_perm(t, offx, sel));
+    };
     auto issue = [&](int u) {
         const int j = u >> 1, k = u & 1;
         wa[k] = (u & 1) ? d[j].z : d[j].x;
         wb[k] = (u & 1) ? d[j].w : d[j].y;
         const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lm[j], tb = (wb[k] & 0x7F7F7F7Fu) | lm[j];
-        e[k][0] = lut_at(lut, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lut, ta, off, 0x0C0C0500u);
-        e[k][2] = lut_at(lut, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lut, ta, off, 0x0C0C0700u);
-        e[k][4] = lut_at(lut, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lut, tb, off, 0x0C0C0500u);
-        e[k][6] = lut_at(lut, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lut, tb, off, 0x0C0C0700u);
+        e[k][0] = lut(ta, 0x0C010400u); e[k][1] = lut(ta, 0x0C010500u); e[k][2] = lut(ta, 0x0C010600u); e[k][3] = lut(ta, 0x0C010700u);
+        e[k][4] = lut(tb, 0x0C010400u); e[k][5] = lut(tb, 0x0C010500u); e[k][6] = lut(tb, 0x0C010600u); e[k][7] = lut(tb, 0x0C010700u);
     };
-    auto recode4 = [&](uint32_t w, const uint2 &e0, const uint2 &e1, const uint2 &e2, const uint2 &e3, const uint8_t *tab) {
-        // decoded PCM value of each code (sign bit set = positive), then the compressor on that value:
-        // the table-driven form of enc_uni (cell lookup in LDS), valid for ANY int16, not only decoder outputs
-        const int x0 = (w & 0x80u) ? (int)e0.y : -(int)e0.y, x1 = (w & 0x8000u) ? (int)e1.y : -(int)e1.y;
-        const int x2 = (w & 0x800000u) ? (int)e2.y : -(int)e2.y, x3 = (w & 0x80000000u) ? (int)e3.y : -(int)e3.y;
-        return (uint32_t)tab[enc_cell<VARIANT>(x0)] | ((uint32_t)tab[enc_cell<VARIANT>(x1)] << 8) |
-               ((uint32_t)tab[enc_cell<VARIANT>(x2)] << 16) | ((uint32_t)tab[enc_cell<VARIANT>(x3)] << 24);
+    // compressor cell of sample i of word w: (|x| >> 2) | law << 14 comes straight from entry.y, the sign from the code
+    auto cells = [&](uint32_t w, const uint2 &e0, const uint2 &e1, const uint2 &e2, const uint2 &e3, uint32_t *dst) {
+        const uint32_t nw = ~w & 0x80808080u;                    // bit 8i+7 set: sample i is negative
+        dst[0] = smem[((nw << 6) & 0x2000u) | (e0.y >> 2)];
+        dst[1] = smem[((nw >> 2) & 0x2000u) | (e1.y >> 2)];
+        dst[2] = smem[((nw >> 10) & 0x2000u) | (e2.y >> 2)];
+        dst[3] = smem[((nw >> 18) & 0x2000u) | (e3.y >> 2)];
     };
+    auto pack = [&](const uint32_t *b) { return b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24); };
     uint32_t sum = 0, peak = 0, bsum = 0;
     uint32_t o[4];
     issue(0);
 #pragma unroll
-    for (int u = 0; u < 2 * kLoadsPerChunk; ++u) {
+    for (int u = 0; u <= 2 * kLoadsPerChunk; ++u) {
         const int j = u >> 1, k = u & 1;
         if (u + 1 < 2 * kLoadsPerChunk) issue(u + 1);
         __builtin_amdgcn_sched_barrier(0);
-        const uint8_t *ek = enc_tab + (lm[j] != 0u ? kEncCells : 0);
-        bsum = __builtin_amdgcn_sad_u8(wa[k], 0u, bsum);
-        bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
-        sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
-        sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
-        peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
-        peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
-        o[2 * k] = recode4(wa[k], e[k][0], e[k][1], e[k][2], e[k][3], ek);
-        o[2 * k + 1] = recode4(wb[k], e[k][4], e[k][5], e[k][6], e[k][7], ek);
-        if (k == 1) {
-            strip_half[j * 64 + lane] = make_uint2(sum, peak | (bsum << 16) | probe_fail(d[j], pm[j]));
-            st_stream(out_half + j * 64, make_uint4(o[0], o[1], o[2], o[3]));
-            if (do_refill) d[j] = ld_stream(refill + j * 64);
-            sum = 0; peak = 0; bsum = 0;
+        if (u < 2 * kLoadsPerChunk) {
+            bsum = __builtin_amdgcn_sad_u8(wa[k], 0u, bsum);
+            bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
+            sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
+            sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
+            peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
+            peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
+            cells(wa[k], e[k][0], e[k][1], e[k][2], e[k][3], &eb[k][0]);
+            cells(wb[k], e[k][4], e[k][5], e[k][6], e[k][7], &eb[k][4]);
+            if (k == 1) {
+                strip_half[j * 64 + lane] = make_uint2(sum, (peak & 0x7FFFu) | (bsum << 16) | probe_fail(d[j], pm[j]));
+                d[j] = ld_stream(refill + j * 64);
+                sum = 0; peak = 0; bsum = 0;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (u >= 1) {                                            // unit u-1: its cell bytes have had a whole fold to arrive
+            const int jp = (u - 1) >> 1, kp = (u - 1) & 1;
+            o[2 * kp] = pack(&eb[kp][0]);
+            o[2 * kp + 1] = pack(&eb[kp][4]);
+            if (kp == 1) st_stream(out_half + jp * 64, make_uint4(o[0], o[1], o[2], o[3]));
         }
     }
 }
@@ -1186,15 +1230,14 @@ __global__ __launch_bounds__(kRtWaves * 64) void k_roundtrip_chunk64(
     // hold records outright (plain read-modify-write).  n_seg > 1: each item folds its own window and MERGES it into
     // hold[c] with device-scope integer atomics (adds, and a CAS loop on the {peak_hold, max, min} word) —
     // exact and order-independent, so the result is bit-identical to the sequential fold.
-    __shared__ uint2 lds[kLutEntries + kRtWaves * kStripEntries];
-    __shared__ uint8_t enc_tab[2 * kEncCells];
-    fill_lut(lds);
-    fill_enc_table<VARIANT>(enc_tab);
+    __shared__ __attribute__((aligned(16))) uint8_t smem[kRtLdsBytes];
+    fill_rt_tables<VARIANT>(smem);
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2 *strip = lds + kLutEntries + wave * kStripEntries;
-    const uint32_t off = (lane & 31u) * 8u;
+    uint2 *strip = reinterpret_cast<uint2 *>(smem + (wave < (uint32_t)(kRtWaves / 2) ? kRtStripA + wave * kRtStripBytes
+                                                                                     : kRtStripB + (wave - (uint32_t)(kRtWaves / 2)) * kRtStripBytes));
+    const uint32_t offx = (lane & 31u) * 8u | 0x100u;
     uint32_t fr[kLoadsPerChunk], pm[kLoadsPerChunk];
 #pragma unroll
     for (int j = 0; j < kLoadsPerChunk; ++j) {
@@ -1237,8 +1280,8 @@ __global__ __launch_bounds__(kRtWaves * 64) void k_roundtrip_chunk64(
             const bool more = f + 1u < f_hi;                    // wave-uniform; the last frame re-reads itself (cache hit)
             const uint4 *nsrc = src + (uint64_t)(more ? f + 1u : f) * fstride16;
             uint4 *o16 = dst + (uint64_t)f * fstride16;
-            roundtrip_half<VARIANT>(lds, strip, X, lm0, pm, off, lane, o16, nsrc, true, enc_tab);
-            roundtrip_half<VARIANT>(lds, strip + kPiecesPerChunk, Y, lm1, pm, off, lane, o16 + kPiecesPerChunk, nsrc + kPiecesPerChunk, true, enc_tab);
+            roundtrip_half<VARIANT>(smem, strip, X, lm0, pm, offx, lane, o16, nsrc);
+            roundtrip_half<VARIANT>(smem, strip + kPiecesPerChunk, Y, lm1, pm, offx, lane, o16 + kPiecesPerChunk, nsrc + kPiecesPerChunk);
             wave_lds_fence();
             {
                 const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kPiecesPerFrame);
