@@ -1099,6 +1099,87 @@ __global__ __launch_bounds__(1024) void k_encode_v8_table(const int16_t *__restr
     for (; g < n_groups; g += stride) encode_group(g, ld_stream(src + g));
 }
 
+// Large batches: the compressor as a FULL 16-bit table, tab[law][uint16(v)] = 128 KiB of LDS built per block by
+// enc_uni (one block per CU, 16 waves).  The whole LDS address {law, v.hi, v.lo} is one v_perm_b32 of the loaded
+// PCM word, so a sample costs ~2 VALU + one ds_read_u8 and the kernel sits on the copy-like HBM bound.  Frame /
+// channel bookkeeping is incremental (adds and compares): the grid-stride step is decomposed once per thread into
+// whole frames + groups, so no division runs inside the loop.
+template <int VARIANT>
+__global__ __launch_bounds__(1024) void k_encode_lut16(const int16_t *__restrict__ pcm, const uint8_t *__restrict__ codec,
+                                                       uint32_t C, uint32_t n, uint64_t n_groups, uint8_t *__restrict__ out)
+{
+    __shared__ uint8_t tab[2 * 65536];
+    {
+        const EncK ku = enc_consts<VARIANT>(false), ka = enc_consts<VARIANT>(true);
+        for (uint32_t i = threadIdx.x; i < 2u * 65536u; i += blockDim.x)
+            tab[i] = (uint8_t)enc_uni<VARIANT>((int)(int16_t)(i & 0xFFFFu), (i >> 16) ? ka : ku);
+    }
+    __syncthreads();
+    const uint32_t gpf = n >> 3;                                   // 8-sample groups per frame
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    auto encode_group = [&](uint64_t gi, const uint4 d, uint32_t pt) {
+        const uint32_t law = pt == IGDSP_PT_PCMA ? 1u : 0u;        // becomes address byte 2: +64 KiB
+        const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+        uint32_t r[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r[2 * i] = tab[__builtin_amdgcn_perm(w[i], law, 0x0C000504u)];
+            r[2 * i + 1] = tab[__builtin_amdgcn_perm(w[i], law, 0x0C000706u)];
+        }
+        uint2 o;
+        o.x = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+        o.y = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
+        reinterpret_cast<uint2 *>(out)[gi] = o;
+    };
+    const uint4 *src = reinterpret_cast<const uint4 *>(pcm);
+    // A wave walks 8 KiB chunks (kP pieces of 64 x 16 B, contiguous); the waves of a block take neighbouring chunks.
+    // Piece j's register is reloaded from the wave's next chunk as soon as piece j is encoded.
+    constexpr int kP = 8;
+    constexpr uint32_t kChunkGroups = 64u * kP;
+    const uint64_t n_chunks = n_groups / kChunkGroups;
+    const uint64_t n_waves = (uint64_t)gridDim.x * wpb;
+    uint64_t chunk = (uint64_t)blockIdx.x * wpb + wave;
+    if (chunk < n_chunks) {
+        // (channel, group-in-frame) of each piece, advanced by adds: one chunk step = step_c channels + step_r groups
+        const uint64_t step = n_waves * kChunkGroups;
+        const uint32_t step_r = (uint32_t)(step % gpf), step_c = (uint32_t)((step / gpf) % C);
+        const uint64_t g0 = chunk * kChunkGroups + lane;
+        uint32_t gin[kP], cc[kP];
+        gin[0] = (uint32_t)(g0 % gpf); cc[0] = (uint32_t)((g0 / gpf) % C);
+#pragma unroll
+        for (int j = 1; j < kP; ++j) {
+            gin[j] = gin[0] + (64u * j) % gpf; cc[j] = cc[0] + ((64u * j) / gpf) % C;
+            if (gin[j] >= gpf) { gin[j] -= gpf; cc[j] += 1u; }
+            if (cc[j] >= C) cc[j] -= C;
+        }
+        uint4 d[kP];
+        uint32_t pt[kP];
+#pragma unroll
+        for (int j = 0; j < kP; ++j) { d[j] = ld_stream(src + (g0 + 64u * j)); pt[j] = codec[cc[j]]; }
+        for (;;) {
+            const uint64_t next = chunk + n_waves;
+            const bool has_next = next < n_chunks;
+            const uint64_t gl = (has_next ? next : chunk) * kChunkGroups + lane;   // last round re-reads itself: loads stay unconditional
+            const uint64_t gs = chunk * kChunkGroups + lane;
+#pragma unroll
+            for (int j = 0; j < kP; ++j) {
+                gin[j] += step_r; cc[j] += step_c;
+                if (gin[j] >= gpf) { gin[j] -= gpf; cc[j] += 1u; }
+                if (cc[j] >= C) cc[j] -= C;
+                encode_group(gs + 64u * j, d[j], pt[j]);
+                d[j] = ld_stream(src + (gl + 64u * j));
+                pt[j] = codec[cc[j]];
+            }
+            if (!has_next) break;
+            chunk = next;
+        }
+    }
+    // groups beyond the last whole chunk (< 512): plain grid-stride
+    for (uint64_t g = n_chunks * kChunkGroups + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups;
+         g += (uint64_t)gridDim.x * blockDim.x)
+        encode_group(g, src[g], codec[(uint32_t)((g / gpf) % C)]);
+}
+
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_encode_scalar(const int16_t *__restrict__ pcm, const uint8_t *__restrict__ codec,
                                                        uint32_t C, uint32_t n, uint64_t n_samples, uint8_t *__restrict__ out)
@@ -1745,7 +1826,12 @@ hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t
     const bool v8 = ((n & 7u) == 0u) && ((reinterpret_cast<uintptr_t>(pcm) & 15u) == 0u) &&
                     ((reinterpret_cast<uintptr_t>(out) & 7u) == 0u);
     const uint32_t cap = (uint32_t)cfg.compute_units * 8u;
-    if (v8 && n_samples >= (1u << 22)) {                        // big batches: table-driven compressor, persistent blocks
+    if (v8 && n_samples >= (1u << 25)) {                        // large batches: full 16-bit table, one block per CU
+        const uint64_t groups = n_samples >> 3;
+        const uint32_t grid = blocks_for(groups, 1024, (uint32_t)cfg.compute_units);
+        if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_G191>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, groups, out);
+        else                           hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_SUN16>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, groups, out);
+    } else if (v8 && n_samples >= (1u << 22)) {                 // big batches: table-driven compressor, persistent blocks
         const uint64_t groups = n_samples >> 3;
         const uint32_t grid = blocks_for(groups, 1024, (uint32_t)cfg.compute_units * 2u);
         if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_v8_table<IGDSP_ENC_G191>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, groups, out);

@@ -202,6 +202,23 @@ def test_encode_large_batch_table_path(ctx, orc, variant):
     assert np.array_equal(gu.to_host(d_out, np.uint8, (F_, C_, n)), orc.encode(pcm, codec, variant))
 
 
+@pytest.mark.parametrize("variant", [capi.ENC_SUN16, capi.ENC_G191])
+@pytest.mark.parametrize("C_,F_,n", [(64, 2048, 256), (96, 2200, 160), (7, 30001, 160)])
+def test_encode_huge_batch_full_table_path(ctx, orc, variant, C_, F_, n):
+    """Batches of >= 32 M samples take k_encode_lut16 (full 16-bit table in LDS, incremental frame/channel bookkeeping):
+    every int16 value, both laws, channel counts that are not powers of two."""
+    torch = gu.torch_cuda()
+    total = C_ * F_ * n
+    assert total >= 1 << 25
+    base = np.arange(-32768, 32768, dtype=np.int32).astype("<i2")
+    pcm = np.resize(np.concatenate([base, base[::-1][:65521]]), total).reshape(F_, C_, n)     # period coprime to the frame size
+    codec = np.where(np.arange(C_) % 3 == 1, 8, 0).astype(np.uint8)
+    d_out = gu.dev_zeros(total, 0xEE)
+    ctx.encode(gu.to_dev(pcm), gu.to_dev(codec), C_, F_, n, d_out, variant=variant)
+    torch.cuda.synchronize()
+    assert np.array_equal(gu.to_host(d_out, np.uint8, (F_, C_, n)), orc.encode(pcm, codec, variant))
+
+
 @pytest.mark.parametrize("n", [160, 7, 200])
 def test_encode_shapes(ctx, orc, n):
     torch = gu.torch_cuda()
