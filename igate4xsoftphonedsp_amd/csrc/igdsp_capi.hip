@@ -502,6 +502,16 @@ int igdsp_internal_stream_rw(igdsp_ctx *ctx, const void *d_src, size_t bytes, vo
     return IGDSP_OK;
 }
 
+// Calibration-only (not in include/igdsp.h): bare read : write mix, r and w 1 KiB pieces per wave item
+// (pairs built: 0:8, 8:8, 8:4, 4:8, 10:1, 10:0, 8:1, 8:2); src needs n_items * r KiB, dst n_items * w KiB.
+int igdsp_internal_stream_mix(igdsp_ctx *ctx, const void *d_src, void *d_dst, uint32_t n_items, int r, int w, void *stream)
+{
+    if (!ctx || !d_src || !d_dst || (reinterpret_cast<uintptr_t>(d_src) & 15u) || (reinterpret_cast<uintptr_t>(d_dst) & 15u)) return IGDSP_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_stream_mix(cfg_of(ctx), d_src, d_dst, n_items, r, w, pick(ctx, stream)));
+    return IGDSP_OK;
+}
+
 // Diagnostic-only (not in include/igdsp.h): cycle stamps of the chunk32 kernel, 8 x u64 per wavefront
 // {t_begin, t_lut_ready, t_end, sum load-wait, sum process, iterations, sum frame-reduce, xcc id}.
 int igdsp_internal_diag_chunk32(igdsp_ctx *ctx, const uint8_t *d_payload, const uint8_t *d_codec, uint32_t C, uint32_t F,

@@ -1737,6 +1737,29 @@ __global__ __launch_bounds__(kBlockThreads) void k_stream_rw(const uint4 *__rest
     }
 }
 
+// Calibration of read : write mixes: every wave reads R and writes W contiguous 1 KiB pieces per item (16 neighbouring
+// items per block), nothing else.  <0,W> is a pure write stream, <R,R> a copy, <10,1> the meter's mix.
+template <int R, int W>
+__global__ __launch_bounds__(kBlockThreads) void k_stream_mix(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n_items)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t b = blockIdx.x; b * kWavesPerBlock + wave < n_items; b += gridDim.x) {
+        const uint32_t item = b * kWavesPerBlock + wave;
+        uint4 acc = make_uint4(item, lane, 0u, 0u);
+        if (R > 0) {
+            const uint4 *p = src + ((uint64_t)item * (uint32_t)(R * 64) + lane);
+            uint4 v[R > 0 ? R : 1];
+#pragma unroll
+            for (int j = 0; j < R; ++j) v[j] = ld_stream(p + j * 64);
+#pragma unroll
+            for (int j = 0; j < R; ++j) { acc.x ^= v[j].x; acc.y ^= v[j].y; acc.z ^= v[j].z; acc.w ^= v[j].w; }
+        }
+        uint4 *q = dst + ((uint64_t)item * (uint32_t)(W * 64) + lane);
+#pragma unroll
+        for (int j = 0; j < W; ++j) q[j * 64] = acc;
+    }
+}
+
 // ============================================================================
 // launchers
 // ============================================================================
@@ -1923,6 +1946,17 @@ hipError_t launch_stream_rw(const LaunchCfg &cfg, const void *src, size_t bytes,
     hipLaunchKernelGGL(k_stream_rw, dim3(cfg.compute_units), dim3(kBlockThreads), 0, s, reinterpret_cast<const uint4 *>(src), n_super,
                        reinterpret_cast<uint4 *>(dst));
     return hipGetLastError();
+}
+
+hipError_t launch_stream_mix(const LaunchCfg &cfg, const void *src, void *dst, uint32_t n_items, int r, int w, hipStream_t s)
+{
+    const dim3 g(cfg.compute_units), b(kBlockThreads);
+    const uint4 *sp = reinterpret_cast<const uint4 *>(src);
+    uint4 *dp = reinterpret_cast<uint4 *>(dst);
+#define IGDSP_MIX(R, W) if (r == R && w == W) { hipLaunchKernelGGL((k_stream_mix<R, W>), g, b, 0, s, sp, dp, n_items); return hipGetLastError(); }
+    IGDSP_MIX(0, 8) IGDSP_MIX(8, 8) IGDSP_MIX(8, 4) IGDSP_MIX(4, 8) IGDSP_MIX(10, 1) IGDSP_MIX(10, 0) IGDSP_MIX(8, 1) IGDSP_MIX(8, 2)
+#undef IGDSP_MIX
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_stream_read(const LaunchCfg &cfg, const void *src, size_t bytes, uint64_t *sink, hipStream_t s)

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Measured ceilings of this box's memory system for read : write mixes (bare load/store kernels, no compute):
+prints one JSON object {mix: GB/s}.  Used to put the kernels' roofline fractions in context."""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from igate4xsoftphonedsp_amd import capi  # noqa: E402
+
+
+def main():
+    ctx = capi.Context(device=0, max_channels=64)
+    fn = ctx.L.igdsp_internal_stream_mix
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+    n_items = 131072                                    # x up to 10 KiB = 1.34 GB, the headline batch
+    src = torch.empty((n_items * 10 * 1024,), dtype=torch.uint8, device="cuda")
+    dst = torch.empty((n_items * 8 * 1024,), dtype=torch.uint8, device="cuda")
+    ctx.gen_uniform(src, src.numel(), seed=1)
+    torch.cuda.synchronize()
+    out = {}
+    for r, w in [(0, 8), (8, 8), (8, 4), (4, 8), (10, 1), (8, 1), (8, 2)]:
+        for _ in range(3):
+            assert fn(ctx.h, src.data_ptr(), dst.data_ptr(), n_items, r, w, None) == 0
+        torch.cuda.synchronize()
+        tm = ctx.timer()
+        reps = 20
+        tm.start(None)
+        for _ in range(reps):
+            fn(ctx.h, src.data_ptr(), dst.data_ptr(), n_items, r, w, None)
+        tm.stop(None)
+        ms = tm.elapsed_ms() / reps
+        out[f"read{r}:write{w}"] = {"ms": round(ms, 4), "GBs": round(n_items * (r + w) * 1024 / (ms * 1e-3) / 1e9, 1),
+                                    "read_GB": round(n_items * r * 1024 / 1e9, 3), "write_GB": round(n_items * w * 1024 / 1e9, 3)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
