@@ -1742,9 +1742,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_stream_rw(const uint4 *__rest
 template <int R, int W>
 __global__ __launch_bounds__(kBlockThreads) void k_stream_mix(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n_items)
 {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t b = blockIdx.x; b * kWavesPerBlock + wave < n_items; b += gridDim.x) {
-        const uint32_t item = b * kWavesPerBlock + wave;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    for (uint32_t b = blockIdx.x; b * wpb + wave < n_items; b += gridDim.x) {
+        const uint32_t item = b * wpb + wave;
         uint4 acc = make_uint4(item, lane, 0u, 0u);
         if (R > 0) {
             const uint4 *p = src + ((uint64_t)item * (uint32_t)(R * 64) + lane);
@@ -1948,13 +1948,14 @@ hipError_t launch_stream_rw(const LaunchCfg &cfg, const void *src, size_t bytes,
     return hipGetLastError();
 }
 
-hipError_t launch_stream_mix(const LaunchCfg &cfg, const void *src, void *dst, uint32_t n_items, int r, int w, hipStream_t s)
+hipError_t launch_stream_mix(const LaunchCfg &cfg, const void *src, void *dst, uint32_t n_items, int r, int w, int waves, hipStream_t s)
 {
-    const dim3 g(cfg.compute_units), b(kBlockThreads);
+    if (waves < 1 || waves > 16) return hipErrorInvalidValue;
+    const dim3 g(cfg.compute_units), b(waves * 64);
     const uint4 *sp = reinterpret_cast<const uint4 *>(src);
     uint4 *dp = reinterpret_cast<uint4 *>(dst);
 #define IGDSP_MIX(R, W) if (r == R && w == W) { hipLaunchKernelGGL((k_stream_mix<R, W>), g, b, 0, s, sp, dp, n_items); return hipGetLastError(); }
-    IGDSP_MIX(0, 8) IGDSP_MIX(8, 8) IGDSP_MIX(8, 4) IGDSP_MIX(4, 8) IGDSP_MIX(10, 1) IGDSP_MIX(10, 0) IGDSP_MIX(8, 1) IGDSP_MIX(8, 2)
+    IGDSP_MIX(0, 8) IGDSP_MIX(8, 8) IGDSP_MIX(8, 4) IGDSP_MIX(4, 8) IGDSP_MIX(10, 1) IGDSP_MIX(10, 0) IGDSP_MIX(8, 1) IGDSP_MIX(8, 2) IGDSP_MIX(20, 2) IGDSP_MIX(5, 1)
 #undef IGDSP_MIX
     return hipErrorInvalidValue;
 }

@@ -16,25 +16,29 @@ def main():
     ctx = capi.Context(device=0, max_channels=64)
     fn = ctx.L.igdsp_internal_stream_mix
     fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
     n_items = 131072                                    # x up to 10 KiB = 1.34 GB, the headline batch
     src = torch.empty((n_items * 10 * 1024,), dtype=torch.uint8, device="cuda")
-    dst = torch.empty((n_items * 8 * 1024,), dtype=torch.uint8, device="cuda")
+    dst = torch.empty((n_items * 10 * 1024,), dtype=torch.uint8, device="cuda")
     ctx.gen_uniform(src, src.numel(), seed=1)
     torch.cuda.synchronize()
     out = {}
-    for r, w in [(0, 8), (8, 8), (8, 4), (4, 8), (10, 1), (8, 1), (8, 2)]:
+    cases = [(0, 8, 16), (8, 8, 16), (8, 4, 16), (4, 8, 16), (10, 1, 16), (8, 1, 16), (8, 2, 16),
+             (10, 1, 8), (10, 1, 4), (10, 1, 12), (20, 2, 16), (20, 2, 8), (5, 1, 16)]
+    for r, w, wv in cases:
+        n_items = 1342177280 // (max(r, 1) * 1024) if r >= 5 else 131072
+        assert n_items * r * 1024 <= src.numel() and n_items * w * 1024 <= dst.numel()
         for _ in range(3):
-            assert fn(ctx.h, src.data_ptr(), dst.data_ptr(), n_items, r, w, None) == 0
+            assert fn(ctx.h, src.data_ptr(), dst.data_ptr(), n_items, r, w, wv, None) == 0
         torch.cuda.synchronize()
         tm = ctx.timer()
         reps = 20
         tm.start(None)
         for _ in range(reps):
-            fn(ctx.h, src.data_ptr(), dst.data_ptr(), n_items, r, w, None)
+            fn(ctx.h, src.data_ptr(), dst.data_ptr(), n_items, r, w, wv, None)
         tm.stop(None)
         ms = tm.elapsed_ms() / reps
-        out[f"read{r}:write{w}"] = {"ms": round(ms, 4), "GBs": round(n_items * (r + w) * 1024 / (ms * 1e-3) / 1e9, 1),
+        out[f"read{r}:write{w}@{wv}waves"] = {"ms": round(ms, 4), "GBs": round(n_items * (r + w) * 1024 / (ms * 1e-3) / 1e9, 1),
                                     "read_GB": round(n_items * r * 1024 / 1e9, 3), "write_GB": round(n_items * w * 1024 / 1e9, 3)}
     print(json.dumps(out))
 
