@@ -1456,21 +1456,20 @@ __global__ __launch_bounds__(256) void k_hold_reset(igdsp_chan_hold *__restrict_
 // ============================================================================
 struct FrameHdr { uint32_t len; igdsp_rtp_info info; };
 
-__device__ __forceinline__ FrameHdr parse_rtp(const uint8_t *pkt, uint32_t size, uint32_t hdr, bool radio, uint32_t n)
+__device__ __forceinline__ FrameHdr parse_rtp_words(uint32_t w0, uint32_t w3, uint32_t w4, uint32_t size, uint32_t hdr, bool radio, uint32_t n)
 {
+    // w0 = packet bytes 0-3, w3 = bytes 12-15 (extension profile / length), w4 = bytes 16-19 (ED-137 word); w3 / w4 are
+    // only looked at for radio packets of at least 20 bytes
     FrameHdr r;
     r.len = 0; r.info.ed137 = 0; r.info.payload_len = 0; r.info.pt = 0; r.info.flags = 0;
-    const uint32_t *w = reinterpret_cast<const uint32_t *>(pkt);
     if (size < hdr) {
         r.info.flags = IGDSP_RTP_RUNT;
-        if (size >= 2u) r.info.pt = (uint8_t)((w[0] >> 8) & 0x7Fu);
+        if (size >= 2u) r.info.pt = (uint8_t)((w0 >> 8) & 0x7Fu);
         return r;
     }
-    const uint32_t w0 = w[0];
     const uint32_t pt = (w0 >> 8) & 0x7Fu;
     uint32_t fl = (((w0 >> 6) & 3u) == 2u ? IGDSP_RTP_V2 : 0u) | ((w0 & 0x10u) ? IGDSP_RTP_X : 0u) | ((w0 & 0x8000u) ? IGDSP_RTP_MARKER : 0u);
     if (radio) {
-        const uint32_t w3 = w[3], w4 = w[4];
         if (pt == 8u || pt == 0u || pt == 18u || pt == 123u) r.info.ed137 = __builtin_bswap32(w4);   // ntohl
         if ((w0 & 0x10u) && w3 == 0x01006701u) fl |= IGDSP_RTP_ED137_OK;                               // bytes 01 67 00 01
     }
@@ -1480,6 +1479,86 @@ __device__ __forceinline__ FrameHdr parse_rtp(const uint8_t *pkt, uint32_t size,
     else if ((pt == 0u || pt == 8u) && pl > 0u) { fl |= IGDSP_RTP_METERED; r.len = pl; }
     r.info.pt = (uint8_t)pt; r.info.payload_len = (uint16_t)pl; r.info.flags = (uint8_t)fl;
     return r;
+}
+
+__device__ __forceinline__ FrameHdr parse_rtp(const uint8_t *pkt, uint32_t size, uint32_t hdr, bool radio, uint32_t n)
+{
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(pkt);
+    const bool wide = radio && size >= hdr;
+    return parse_rtp_words(w[0], wide ? w[3] : 0u, wide ? w[4] : 0u, size, hdr, radio, n);
+}
+
+// Tuned n == 160 form: a wave takes 64 consecutive packets.  Twelve dword-aligned 16-byte pieces per packet (bytes
+// [0,16) and [4,20) of the header, then the ten payload pieces at hdr + 16 k) are spread over the lanes exactly as in
+// k_meter_rtp64, so every load instruction covers ~5 whole packets.  The header pieces hand {bytes 0-3, ext word,
+// ED-137 word} to the packet's frame lane through LDS; the frame lane parses once per packet (instead of once per
+// piece), writes len / info coalesced and publishes the payload length; each payload piece then masks and stores
+// itself into the dense output (one contiguous run per store instruction).
+constexpr int kDpWaves = 4;
+__global__ __launch_bounds__(kDpWaves * 64, 4) void k_depayload64(const uint8_t *__restrict__ packets, const uint16_t *__restrict__ sizes,
+                                                               const uint8_t *__restrict__ radio, uint32_t C, uint32_t n_frames,
+                                                               uint32_t stride, uint8_t *__restrict__ payload,
+                                                               uint16_t *__restrict__ len, igdsp_rtp_info *__restrict__ info)
+{
+    __shared__ uint4 hdrs[kDpWaves][64];          // per packet {bytes 0-3, -, ext word, ED-137 word}; .y reused for the parsed length
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint4 *hw = hdrs[wave];
+    const uint32_t n_super = n_frames / kSuperFrames;
+    const uint32_t total_waves = gridDim.x * kDpWaves;
+    for (uint32_t sidx = blockIdx.x * kDpWaves + wave; sidx < n_super; sidx += total_waves) {
+        // piece p = j * 64 + lane of the item -> packet fr = p / 12, piece q = p % 12.  Recomputed from an opaque copy of
+        // the lane id in each phase: hoisting all 12 x 3 sets of lane constants out of the loop costs more registers
+        // (and spills) than the few VALU ops they take.
+        uint32_t ln = lane;
+        asm volatile("" : "+v"(ln));
+        const uint32_t f0 = sidx * kSuperFrames, fi = f0 + lane;
+        const bool my_radio = radio[fi % C] != 0;
+        const uint32_t my_size = min(sizes ? (uint32_t)sizes[fi] : stride, stride);
+        const uint64_t rmask = __ballot(my_radio);
+        const uint8_t *base = packets + (uint64_t)f0 * stride;                       // wave-uniform bases, 32-bit lane offsets
+        uint4 *ob = reinterpret_cast<uint4 *>(payload) + (uint64_t)f0 * kPiecesPerFrame;
+        uint4 d[kSlotPieces];
+#pragma unroll
+        for (int j = 0; j < kSlotPieces; ++j) {
+            const uint32_t p = (uint32_t)j * 64u + ln, fr = p / 12u, q = p - fr * 12u;
+            const uint32_t hb = (uint32_t)((rmask >> fr) & 1ull);
+            const uint32_t po = q == 0u ? 0u : (q == 1u ? 4u : 12u + 8u * hb + 16u * (q - 2u));
+            d[j] = ld16_dw(base + (fr * stride + po));
+        }
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int j = 0; j < kSlotPieces; ++j) {
+            const uint32_t p = (uint32_t)j * 64u + ln, fr = p / 12u, q = p - fr * 12u;
+            if (q < 2u)                              // piece 0 -> {.x = bytes 0-3, .y = 0}; piece 1 -> {.z = ext word, .w = ED-137 word}
+                reinterpret_cast<uint2 *>(&hw[fr])[q] = q == 0u ? make_uint2(d[j].x, 0u) : make_uint2(d[j].z, d[j].w);
+        }
+        wave_lds_fence();
+        {
+            const uint4 h = hw[lane];
+            const FrameHdr r = parse_rtp_words(h.x, h.z, h.w, my_size, my_radio ? 20u : 12u, my_radio, (uint32_t)kFrame);
+            len[fi] = (uint16_t)r.len;
+            info[fi] = r.info;
+            hw[lane].y = r.len;
+        }
+        wave_lds_fence();
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int j = 0; j < kSlotPieces; ++j) {
+            const uint32_t p = (uint32_t)j * 64u + ln, fr = p / 12u, q = p - fr * 12u;
+            if (q >= 2u) {
+                const uint32_t flen = hw[fr].y, b0 = 16u * (q - 2u);
+                const uint32_t nb = flen > b0 ? min(flen - b0, 16u) : 0u;
+                uint32_t x[4] = {d[j].x, d[j].y, d[j].z, d[j].w};
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {  // keep the first nb bytes of the piece, branch-free
+                    const uint32_t bits = 8u * (nb > 4u * k ? min(nb - 4u * k, 4u) : 0u);
+                    x[k] &= (uint32_t)((1ull << bits) - 1ull);
+                }
+                ob[fr * (uint32_t)kPiecesPerFrame + (q - 2u)] = make_uint4(x[0], x[1], x[2], x[3]);
+            }
+        }
+        wave_lds_fence();
+    }
 }
 
 __global__ __launch_bounds__(256) void k_depayload16(const uint8_t *__restrict__ packets, const uint16_t *__restrict__ sizes,
@@ -1922,7 +2001,12 @@ hipError_t launch_depayload(const LaunchCfg &cfg, const uint8_t *packets, const 
     const uint32_t n_frames = C * F;
     if (n_frames == 0) return hipSuccess;
     const uint32_t cap = (uint32_t)cfg.compute_units * 8u;
-    if ((n & 15u) == 0u && (reinterpret_cast<uintptr_t>(payload) & 15u) == 0u) {
+    const bool aligned = (reinterpret_cast<uintptr_t>(payload) & 15u) == 0u;
+    if (aligned && n == (uint32_t)kFrame && (n_frames % kSuperFrames) == 0u && stride >= 180u) {
+        // whole super-chunks of n == 160 packets whose slots hold a full radio packet: header parsed once per packet
+        hipLaunchKernelGGL(k_depayload64, dim3(blocks_for(n_frames / kSuperFrames, kDpWaves, cap)), dim3(kDpWaves * 64), 0, s,
+                           packets, sizes, radio, C, n_frames, stride, payload, len, info);
+    } else if ((n & 15u) == 0u && aligned) {
         const uint64_t pieces = (uint64_t)n_frames * (n >> 4);
         hipLaunchKernelGGL(k_depayload16, dim3(blocks_for(pieces, 256, cap)), dim3(256), 0, s, packets, sizes, radio, C, n_frames, stride, n, payload, len, info);
     } else {

@@ -71,6 +71,26 @@ def test_depayload_vs_oracle(ctx, orc, stride, n):
     assert np.array_equal((v & 0xe0000000) >> 29, (ginfo["ed137"].astype(np.uint64) >> 29) & 7)
 
 
+@pytest.mark.parametrize("stride,C_,F_,with_sizes", [(180, 32, 6, True), (184, 96, 4, True), (256, 64, 3, True), (180, 64, 2, False), (192, 192, 1, False)])
+def test_depayload_tuned_path_vs_oracle(ctx, orc, stride, C_, F_, with_sizes):
+    """n == 160 and C*F % 64 == 0 take k_depayload64 (header parsed once per packet, pieces spread like the fused kernel):
+    mixed 12/20-byte headers, runts, oversize, keep-alives, partial lengths, garbage behind short packets."""
+    torch = gu.torch_cuda()
+    n = 160
+    pk, sizes, radio = _make_packets(orc, C_, F_, stride, n, seed=stride * 7 + C_)
+    d_pl, d_len, d_info = gu.dev_zeros(F_ * C_ * n, 0xEE), gu.dev_zeros(F_ * C_ * 2, 0xEE), gu.dev_zeros(F_ * C_ * 8, 0xEE)
+    ctx.depayload(gu.to_dev(pk), gu.to_dev(sizes) if with_sizes else None, gu.to_dev(radio), C_, F_, stride, n, d_pl, d_len, d_info)
+    torch.cuda.synchronize()
+    epl, elen, einfo = orc.depayload(pk, sizes if with_sizes else None, radio, n)
+    assert np.array_equal(gu.to_host(d_len, "<u2", (F_, C_)), elen)
+    ginfo = gu.to_host(d_info, capi.RTP_INFO, (F_, C_))
+    for f in capi.RTP_INFO.names:
+        assert np.array_equal(ginfo[f], einfo[f]), f
+    assert np.array_equal(gu.to_host(d_pl, np.uint8, (F_, C_, n)), epl)
+    if with_sizes:
+        assert ((elen > 0) & (elen < n)).any() and (elen == 0).any() and (elen == n).any()
+
+
 def test_depayload_then_meter_equals_direct(ctx, orc):
     """packets -> igdsp_depayload -> igdsp_decode_meter(len) == oracle meter on the oracle's payloads;
     full 180-byte slots without a size array take the same route."""
