@@ -10,11 +10,11 @@ One "step" = one pass of the hot path (igdsp_decode_meter through the C ABI) ove
 device-resident batch payload[F][C][160] (1.34 GB per GPU: larger than the 256 MB
 Infinity Cache, so the figure is an HBM figure).  Channels shard by contiguous range
 across ranks (weak scaling: 65 536 ch per GPU; N = 8 is BASELINE configs[3], 524 288 ch)
-with ONE 112-byte RCCL all-reduce per launch for the node-wide sum-of-squares / peak,
+with ONE 896-byte RCCL all-reduce per launch for the node-wide sum-of-squares / peak,
 issued on a side stream behind the kernel's event.
 
-Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events on the launch
-stream, `cpu_baseline` is the CPU oracle timed on this box's host cores (N = 1 only).
+Rank 0 prints ONE JSON line; `roofline` is measured live with one pair of HIP events on the launch
+stream around the K timed launches (average launch duration = elapsed / K), `cpu_baseline` is the CPU oracle timed on this box's host cores (N = 1 only).
 """
 from __future__ import annotations
 
@@ -177,37 +177,32 @@ def main():
         ctx.hold_reset(d_hold, C_, stream=hs)
     d_st = torch.zeros((F_ * C_ * 2,), dtype=torch.int64, device="cuda")   # igdsp_frame_stats[F][C]
     d_pcm = torch.empty((F_, C_, n), dtype=torch.int16, device="cuda") if args.mode == "store" else None
-    aggs = [torch.zeros((capi.AGG_WORDS,), dtype=torch.int64, device="cuda") for _ in range(2)]
-    ev_k = [torch.cuda.Event() for _ in range(2)]
-    ev_c = [torch.cuda.Event() for _ in range(2)]
-    timers = [ctx.timer() for _ in range(args.steps)]
+    # one pre-zeroed aggregate per step (896 B each): a launch ADDS into its aggregate, so nothing has to be cleared
+    # between launches and, for N > 1, all-reduce k runs on the side stream on its own buffer while launch k + 1 runs
+    n_steps_total = args.warmup + args.steps
+    agg_ring = torch.zeros((n_steps_total, capi.AGG_WORDS), dtype=torch.int64, device="cuda")
+    ev_k = [torch.cuda.Event() for _ in range(n_steps_total)] if world > 1 else []
+    region = ctx.timer()                             # HIP events on the launch stream around the K timed launches
 
-    def step(i: int, timer=None):
-        b = i & 1
-        main_s.wait_event(ev_c[b])                 # the all-reduce that last used this aggregate buffer is done
-        aggs[b].zero_()
-        if timer is not None:
-            timer.start(hs)
+    def step(i: int):
+        agg = agg_ring[i]
         if args.mode == "encode":
             ctx.encode(d_pcm_in, d_cd, C_, F_, n, d_out, stream=hs)
         elif args.mode == "rtp":
-            ctx.decode_meter_rtp(d_slots, d_cd, C_, F_, d_st, info=d_info, agg=aggs[b], rank=rank, stream=hs)
+            ctx.decode_meter_rtp(d_slots, d_cd, C_, F_, d_st, info=d_info, agg=agg, rank=rank, stream=hs)
         elif args.mode == "packets":
-            ctx.decode_meter_packets(d_slots, None, d_cd, C_, F_, 180, 20, d_st, info=d_info, agg=aggs[b], rank=rank, stream=hs)
+            ctx.decode_meter_packets(d_slots, None, d_cd, C_, F_, 180, 20, d_st, info=d_info, agg=agg, rank=rank, stream=hs)
         elif args.mode == "depayload":
             ctx.depayload(d_pk, None, d_radio, C_, F_, 180, n, d_pl, d_len, d_info, stream=hs)
         elif args.mode == "roundtrip":
             ctx.roundtrip_peakhold(d_pl, d_cd, C_, F_, n, d_out, d_st, d_hold, stream=hs)
         else:
-            ctx.decode_meter(d_pl, d_cd, C_, F_, n, d_st, pcm=d_pcm, agg=None if args.no_agg else aggs[b], rank=rank, stream=hs)
-        if timer is not None:
-            timer.stop(hs)
-        if world > 1:                              # node-wide sum / peak: one 112-byte all-reduce per launch, side stream
-            ev_k[b].record(main_s)
+            ctx.decode_meter(d_pl, d_cd, C_, F_, n, d_st, pcm=d_pcm, agg=None if args.no_agg else agg, rank=rank, stream=hs)
+        if world > 1:                              # node-wide sum / peak: one 896-byte all-reduce per launch, side stream
+            ev_k[i].record(main_s)
             with torch.cuda.stream(comm_s):
-                comm_s.wait_event(ev_k[b])
-                dist.all_reduce(aggs[b], op=dist.ReduceOp.SUM)
-                ev_c[b].record(comm_s)
+                comm_s.wait_event(ev_k[i])
+                dist.all_reduce(agg, op=dist.ReduceOp.SUM)
 
     if world > 1:                                  # communicator / channel setup is not part of any step (holds for --warmup 0 too)
         prime = torch.zeros((capi.AGG_WORDS,), dtype=torch.int64, device="cuda")
@@ -221,8 +216,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    region.start(hs)
     for i in range(args.steps):
-        step(args.warmup + i, timers[i])
+        step(args.warmup + i)
+    region.stop(hs)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -233,14 +230,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    kern_ms = [tm.elapsed_ms() for tm in timers]
-    kern_avg_ms = sum(kern_ms) / len(kern_ms)
-    kern_med_ms = sorted(kern_ms)[len(kern_ms) // 2]
+    # average launch duration: the K launches run back to back on `hs`, bracketed by ONE pair of HIP events on that
+    # stream (bracketing every launch with its own pair adds ~10 us of event handling to each 0.25 ms launch)
+    kern_avg_ms = region.elapsed_ms() / args.steps
 
     # node-wide aggregate from the last launch (after the all-reduce every rank holds all peak slots)
     from igate4xsoftphonedsp_amd import dist as igdist
 
-    node = igdist.node_view(aggs[(args.warmup + args.steps - 1) & 1])
+    node = igdist.node_view(agg_ring[n_steps_total - 1])
 
     samples_per_step_rank = C_ * F_ * n
     total_samples = samples_per_step_rank * world * args.steps
@@ -267,13 +264,13 @@ def main():
                         f"decode+meter ({args.mode}), device-resident {d_pl.numel() / 1e9:.2f} GB/GPU, "
                         f"{'D-speech tile x channels' if args.mode == 'roundtrip' else 'D-uniform seed 0x20241218'}",
             "channels_per_gpu": C_, "channels_total": C_total, "frames_per_launch": F_, "samples_per_frame": n,
-            "sharding": "contiguous channel ranges, no data-path collective; one 112 B all-reduce per launch" if world > 1 else "single GPU",
+            "sharding": "contiguous channel ranges, no data-path collective; one 896 B all-reduce per launch" if world > 1 else "single GPU",
             "kernel_variant": args.variant,
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": kernel_name, "kernel_avg_ms": round(kern_avg_ms, 4), "kernel_median_ms": round(kern_med_ms, 4),
+            "kernel": kernel_name, "kernel_avg_ms": round(kern_avg_ms, 4),
             "algorithmic_bytes_per_sample": round(bps, 5),
             "algorithmic_bytes_per_launch": int(samples_per_step_rank * bps),
         },
@@ -324,8 +321,7 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
 
-    for tm in timers:
-        tm.close()
+    region.close()
     ctx.close()
     if world > 1:
         dist.barrier()

@@ -23,7 +23,8 @@ MAX_PAYLOAD = 256
 ENC_SUN16, ENC_G191 = 0, 1
 FLAG_SILENT, FLAG_PROBE_D5, FLAG_CLIPPED, FLAG_EMPTY = 1, 2, 4, 8
 AGG_MAX_RANKS = 8
-AGG_WORDS = 6 + AGG_MAX_RANKS
+AGG_LINE_WORDS = 16
+AGG_WORDS = 7 * AGG_LINE_WORDS
 
 ERRORS = {
     0: "IGDSP_OK", -22: "IGDSP_EINVAL", -12: "IGDSP_ENOMEM", -19: "IGDSP_ENODEV", -2: "IGDSP_ENOENT",
@@ -41,10 +42,12 @@ CHAN_HOLD = np.dtype(
 )
 RTP_INFO = np.dtype([("ed137", "<u4"), ("payload_len", "<u2"), ("pt", "u1"), ("flags", "u1")], align=True)
 RTP_V2, RTP_X, RTP_MARKER, RTP_ED137_OK, RTP_KEEPALIVE, RTP_METERED, RTP_RUNT, RTP_OVERSIZE = 1, 2, 4, 8, 16, 32, 64, 128
-AGGREGATE = np.dtype(
-    [("sumsq", "<u8"), ("samples", "<u8"), ("frames", "<u8"), ("n_silent", "<u8"), ("n_clipped", "<u8"),
-     ("byte_mean_sum", "<u8"), ("peak_slot", "<u8", (AGG_MAX_RANKS,))]
-)
+AGGREGATE = np.dtype({      # one 128-byte line per counter (include/igdsp.h); the padding is not exposed as fields
+    "names": ["sumsq", "samples", "frames", "n_silent", "n_clipped", "byte_mean_sum", "peak_slot"],
+    "formats": ["<u8", "<u8", "<u8", "<u8", "<u8", "<u8", ("<u8", (AGG_MAX_RANKS,))],
+    "offsets": [128 * i for i in range(7)],
+    "itemsize": 8 * AGG_WORDS,
+})
 
 
 class Level(C.Structure):

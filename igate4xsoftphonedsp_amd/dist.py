@@ -18,9 +18,9 @@ def channel_range(n_channels: int, rank: int, world: int) -> tuple[int, int]:
 
 
 def allreduce_aggregate(vec: torch.Tensor, async_op: bool = False):
-    """Sum-all-reduce the packed aggregate in place (int64[14]; device tensor under nccl) and return the
+    """Sum-all-reduce the packed aggregate in place (int64[capi.AGG_WORDS]; device tensor under nccl) and return the
     node-wide view.  Rank g's peak sits alone in peak_slot[g], so the SUM also delivers every rank's
-    peak and the max is taken locally: sums and max in one collective of 112 bytes."""
+    peak and the max is taken locally: sums and max in one collective of 896 bytes (each counter sits on its own 128-byte line, zero padding between)."""
     assert vec.dtype == torch.int64 and vec.numel() == capi.AGG_WORDS
     work = None
     if dist.is_initialized() and dist.get_world_size() > 1:
@@ -32,8 +32,9 @@ def allreduce_aggregate(vec: torch.Tensor, async_op: bool = False):
 
 def node_view(vec: torch.Tensor) -> dict:
     v = [int(x) & 0xFFFFFFFFFFFFFFFF for x in vec.cpu().tolist()]
-    samples = max(v[1], 1)
+    L = capi.AGG_LINE_WORDS                                   # counter k lives in word k * L
+    samples = max(v[1 * L], 1)
     return {
-        "sumsq": v[0], "samples": v[1], "frames": v[2], "n_silent": v[3], "n_clipped": v[4], "byte_mean_sum": v[5],
-        "peak": max(v[6:]), "rms": math.sqrt(v[0] / samples),
+        "sumsq": v[0], "samples": v[1 * L], "frames": v[2 * L], "n_silent": v[3 * L], "n_clipped": v[4 * L],
+        "byte_mean_sum": v[5 * L], "peak": max(v[6 * L:6 * L + capi.AGG_MAX_RANKS]), "rms": math.sqrt(v[0] / samples),
     }

@@ -111,16 +111,22 @@ typedef struct igdsp_chan_hold {
  * sum all-reduce (RCCL ncclSum over int64) yields sums AND the max: rank g writes
  * its local peak only into peak_slot[g]; after the sum every rank holds all peaks. */
 #define IGDSP_AGG_MAX_RANKS 8
+/* Every counter owns a 128-byte line: a persistent launch ends with one device atomic per block per counter, and
+ * atomics on ONE line serialise (~95 per microsecond) - seven counters sharing a line cost ~8 us per launch on
+ * MI355X, on separate lines ~3 us (tools/agg_ab.py).  The padding is zero, so the struct is still summed as one
+ * vector of IGDSP_AGG_WORDS uint64. */
+#define IGDSP_AGG_LINE_WORDS 16
 typedef struct igdsp_aggregate {
-    uint64_t sumsq;                            /* sum of sumsq over all frames      */
-    uint64_t samples;                          /* samples metered                   */
-    uint64_t frames;                           /* non-empty frames metered          */
-    uint64_t n_silent;
-    uint64_t n_clipped;
-    uint64_t byte_mean_sum;                    /* sum of byte_mean (checksum-of-checksums) */
-    uint64_t peak_slot[IGDSP_AGG_MAX_RANKS];   /* this rank's peak in slot[rank]    */
+    uint64_t sumsq;         uint64_t pad0[IGDSP_AGG_LINE_WORDS - 1];   /* sum of sumsq over all frames      */
+    uint64_t samples;       uint64_t pad1[IGDSP_AGG_LINE_WORDS - 1];   /* samples metered                   */
+    uint64_t frames;        uint64_t pad2[IGDSP_AGG_LINE_WORDS - 1];   /* non-empty frames metered          */
+    uint64_t n_silent;      uint64_t pad3[IGDSP_AGG_LINE_WORDS - 1];
+    uint64_t n_clipped;     uint64_t pad4[IGDSP_AGG_LINE_WORDS - 1];
+    uint64_t byte_mean_sum; uint64_t pad5[IGDSP_AGG_LINE_WORDS - 1];   /* sum of byte_mean (checksum-of-checksums) */
+    uint64_t peak_slot[IGDSP_AGG_MAX_RANKS];                            /* this rank's peak in slot[rank]    */
+    uint64_t pad6[IGDSP_AGG_LINE_WORDS - IGDSP_AGG_MAX_RANKS];
 } igdsp_aggregate;
-#define IGDSP_AGG_WORDS (6 + IGDSP_AGG_MAX_RANKS)
+#define IGDSP_AGG_WORDS (7 * IGDSP_AGG_LINE_WORDS)
 
 /* What igdsp_poll returns for one channel: everything host code needs to fill
  * trx::IncomingRTP (roip_ed137.cpp:6570-6585) and feed updateInputLevel(int percent)

@@ -33,8 +33,9 @@ typedef struct {
     uint64_t sumsq_acc; uint32_t count; uint32_t level_sum; uint32_t samples;
     uint16_t peak_hold; uint8_t level_max; uint8_t level_min; uint32_t n_silent; uint32_t n_clipped;
 } orc_chan_hold;
-typedef struct {
-    uint64_t sumsq, samples, frames, n_silent, n_clipped, byte_mean_sum, peak_slot[8];
+typedef struct {   /* one 128-byte line per counter, as igdsp_aggregate */
+    uint64_t sumsq, pad0[15], samples, pad1[15], frames, pad2[15], n_silent, pad3[15], n_clipped, pad4[15],
+             byte_mean_sum, pad5[15], peak_slot[8], pad6[8];
 } orc_aggregate;
 
 /* G.711 (ITU-T G.711; restated from the standard's segment definition) */

@@ -33,11 +33,13 @@ CHAN_HOLD = np.dtype(
     ],
     align=True,
 )
-AGGREGATE = np.dtype(
-    [("sumsq", "<u8"), ("samples", "<u8"), ("frames", "<u8"), ("n_silent", "<u8"),
-     ("n_clipped", "<u8"), ("byte_mean_sum", "<u8"), ("peak_slot", "<u8", (8,))]
-)
-assert FRAME_STATS.itemsize == 16 and CHAN_HOLD.itemsize == 32 and AGGREGATE.itemsize == 112
+AGGREGATE = np.dtype({
+    "names": ["sumsq", "samples", "frames", "n_silent", "n_clipped", "byte_mean_sum", "peak_slot"],
+    "formats": ["<u8", "<u8", "<u8", "<u8", "<u8", "<u8", ("<u8", (8,))],
+    "offsets": [128 * i for i in range(7)],
+    "itemsize": 896,
+})
+assert FRAME_STATS.itemsize == 16 and CHAN_HOLD.itemsize == 32 and AGGREGATE.itemsize == 896
 
 RTP_INFO = np.dtype([("ed137", "<u4"), ("payload_len", "<u2"), ("pt", "u1"), ("flags", "u1")], align=True)
 assert RTP_INFO.itemsize == 8

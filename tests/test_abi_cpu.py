@@ -35,7 +35,7 @@ def test_header_symbols_all_exported_and_bound(lib):
 def test_struct_layouts_agree(orc):
     assert capi.FRAME_STATS.itemsize == orc.FRAME_STATS.itemsize == 16
     assert capi.CHAN_HOLD.itemsize == orc.CHAN_HOLD.itemsize == 32
-    assert capi.AGGREGATE.itemsize == orc.AGGREGATE.itemsize == 8 * capi.AGG_WORDS == 112
+    assert capi.AGGREGATE.itemsize == orc.AGGREGATE.itemsize == 8 * capi.AGG_WORDS == 896
     assert ctypes.sizeof(capi.Level) == 20
     for a, b in ((capi.FRAME_STATS, orc.FRAME_STATS), (capi.CHAN_HOLD, orc.CHAN_HOLD), (capi.AGGREGATE, orc.AGGREGATE)):
         assert a.names == b.names

@@ -70,4 +70,4 @@ def test_channel_ranges_partition():
         assert spans[0][0] == 0 and spans[-1][1] == C_
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
-    assert capi.AGG_WORDS == 14
+    assert capi.AGG_WORDS == 112 and capi.AGG_LINE_WORDS == 16

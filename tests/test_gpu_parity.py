@@ -537,7 +537,7 @@ def test_channel_sharding_invariance(ctx, orc):
     node = igdist.node_view(torch.from_numpy(vec.view(np.int64)))
     assert node["sumsq"] == int(agg_full["sumsq"]) and node["frames"] == C_ * F_ and node["samples"] == C_ * F_ * n
     assert node["peak"] == int(st_full["peak"].max()) and node["byte_mean_sum"] == int(agg_full["byte_mean_sum"])
-    assert sorted(int(x) for x in vec[6:6 + G]) == sorted(int(st_full["peak"][:, slice(*igdist.channel_range(C_, g, G))].max()) for g in range(G))
+    assert sorted(int(x) for x in vec[6 * capi.AGG_LINE_WORDS:6 * capi.AGG_LINE_WORDS + G]) == sorted(int(st_full["peak"][:, slice(*igdist.channel_range(C_, g, G))].max()) for g in range(G))
 
 
 def test_half_million_channels_one_launch(ctx, orc):
