@@ -482,6 +482,31 @@ int igdsp_stream_read(igdsp_ctx *ctx, const void *d_src, size_t bytes, uint64_t 
     return IGDSP_OK;
 }
 
+int igdsp_probe_placement(igdsp_ctx *ctx, const void *d_buf, size_t bytes, uint32_t reps, float *ms_per_launch, void *stream)
+{
+    if (!ctx || !d_buf || !ms_per_launch || reps == 0 || bytes < 10240u || (reinterpret_cast<uintptr_t>(d_buf) & 15u)) return IGDSP_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    void *scratch = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipMalloc(&scratch, bytes / 10u + 4096u) != hipSuccess) return fail(ctx, IGDSP_ENOMEM, "probe scratch");
+    hipError_t e = hipEventCreate(&a);
+    if (e == hipSuccess) e = hipEventCreate(&b);
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx), d_buf, bytes, scratch, s);
+    if (e == hipSuccess) e = hipEventRecord(a, s);
+    for (uint32_t i = 0; i < reps && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx), d_buf, bytes, scratch, s);
+    if (e == hipSuccess) e = hipEventRecord(b, s);
+    if (e == hipSuccess) e = hipEventSynchronize(b);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    (void)hipFree(scratch);
+    if (e != hipSuccess) return fail(ctx, IGDSP_EDEVICE, "igdsp_probe_placement", e);
+    *ms_per_launch = ms / (float)reps;
+    return IGDSP_OK;
+}
+
 // Test-only (not in include/igdsp.h): the table-driven compressor the fused round-trip kernel uses, on arbitrary PCM.
 int igdsp_internal_encode_table(igdsp_ctx *ctx, const int16_t *d_pcm, const uint8_t *d_codec, uint32_t C, uint32_t F, uint32_t n,
                                 uint8_t *d_out, int variant, void *stream)

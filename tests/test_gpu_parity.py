@@ -560,3 +560,18 @@ def test_half_million_channels_one_launch(ctx, orc):
         e = orc.decode_meter(orc.gen_uniform(n, seed=5, first_byte=int(fi) * n).reshape(1, 1, n), [int(codec[c])])[0, 0]
         g = st[fi]
         assert (int(g["sumsq"]), int(g["peak"]), int(g["byte_mean"]), int(g["flags"])) == (int(e["sumsq"]), int(e["peak"]), int(e["byte_mean"]), int(e["flags"])), fi
+
+
+def test_probe_placement(ctx):
+    """igdsp_probe_placement: a positive per-launch time of the bare read + record stream; argument rules."""
+    import ctypes as C
+    torch = gu.torch_cuda()
+    nbytes = 64 << 20
+    buf = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
+    ms = ctx.probe_placement(buf, nbytes, reps=5)
+    assert 0.0 < ms < 5.0                                     # 64 MiB at >= 15 GB/s even on a throttled box
+    out = C.c_float(0)
+    assert ctx.L.igdsp_probe_placement(ctx.h, buf.data_ptr(), nbytes, 0, C.byref(out), None) == -22      # reps == 0
+    assert ctx.L.igdsp_probe_placement(ctx.h, buf.data_ptr() + 4, nbytes - 4, 5, C.byref(out), None) == -22   # alignment
+    assert ctx.L.igdsp_probe_placement(ctx.h, buf.data_ptr(), 100, 5, C.byref(out), None) == -22          # < one item
+    assert ctx.L.igdsp_probe_placement(ctx.h, None, nbytes, 5, C.byref(out), None) == -22
