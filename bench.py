@@ -57,8 +57,9 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="untimed launches of the step before the W warmup steps until this much GPU time has passed: the "
                          "GPU needs ~20 ms of load to reach its steady clocks (first 30 launches measure ~6 %% slow)")
-    ap.add_argument("--placement-candidates", type=int, default=12,
-                    help="payload slabs to allocate and probe (igdsp_probe_placement); the fastest holds the batch, 1 = take the first")
+    ap.add_argument("--placement-positions", type=int, default=7,
+                    help="candidate positions of the OUTPUT buffers, --spacer-gib apart; the fastest (timed real launches) is kept; 1 = off")
+    ap.add_argument("--spacer-gib", type=float, default=12.0)
     return ap.parse_args()
 
 
@@ -129,58 +130,71 @@ def main():
     hs = main_s.cuda_stream
     assert hs != 0
 
-    # ---- synthetic input, generated on the device, shard-invariant: this rank holds
-    # channels [rank*C, (rank+1)*C) of the global [F][C_total][160] D-uniform array.
-    # Placement: identical device allocations differ by ~10 % in read+record stream rate on MI355X (igdsp.h,
-    # igdsp_probe_placement); like a host would at start-up, allocate a few candidate slabs and keep the fastest.
-    placement = None
-    n_pl = F_ * C_ * n
-    # candidate i carries i x 24 MiB of slack behind the slab so that the allocations do not all have the same size
-    slabs = [torch.empty((n_pl + i * (24 << 20),), dtype=torch.uint8, device="cuda") for i in range(max(1, args.placement_candidates))]
-    cands = [sl[:n_pl].view(F_, C_, n) for sl in slabs]
-    if len(cands) > 1 and n_pl >= (1 << 24):
-        torch.cuda.synchronize()
-        ms = [ctx.probe_placement(c, n_pl, reps=10, stream=hs) for c in cands]
-        best = min(range(len(ms)), key=lambda i: ms[i])
-        placement = {"candidates_ms": [round(x, 4) for x in ms], "chosen": best}
-        d_pl = cands[best]
-    else:
-        d_pl = cands[0]
-    del cands, slabs
-    torch.cuda.empty_cache()
+    # ---- one device arena: inputs at its start, the output set at one of --placement-positions offsets behind them.
+    # Where the outputs sit RELATIVE to the inputs matters on MI355X: a stream that reads one ~70 GB
+    # region of device memory and writes another runs ~13 % faster than one that reads and writes the same region.
+    class Arena:
+        def __init__(self, nbytes):
+            self.t = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
+            self.cur = 0
+
+        def take(self, shape, dtype, zero=False):
+            nb = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+            off = (self.cur + (2 << 20) - 1) & ~((2 << 20) - 1)
+            if off + nb > self.t.numel():
+                raise RuntimeError("bench arena exhausted")
+            self.cur = off + nb
+            v = self.t[off:off + nb].view(dtype).view(shape)
+            if zero:
+                v.zero_()
+            return v
+
+    positions = max(1, args.placement_positions)
+    spacer = int(args.spacer_gib * (1 << 30))
+    arena = None
+    if positions > 1 and F_ * C_ * n >= (1 << 24):
+        try:
+            arena = Arena(F_ * C_ * n * 8 + positions * spacer)      # inputs <= 3 x batch, outputs <= 3 x batch, slack
+        except RuntimeError:
+            arena = None                                              # not enough free device memory: plain allocations
+    if arena is None:
+        positions = 1
+
+    def new(shape, dtype, zero=False):
+        if arena is not None:
+            return arena.take(shape, dtype, zero)
+        return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device="cuda")
+
+    # ---- inputs.  Synthetic, generated on the device, shard-invariant: this rank holds channels
+    # [rank*C, (rank+1)*C) of the global [F][C_total][160] D-uniform array.
+    d_pl = new((F_, C_, n), torch.uint8)
     for f in range(F_):
         first = (f * C_total + rank * C_) * n
         ctx.gen_uniform(d_pl[f], C_ * n, first_byte=first, stream=hs)
-    d_cd = torch.zeros((C_,), dtype=torch.uint8, device="cuda")           # mu-law (RTP PT 0) everywhere
-    d_out = d_hold = d_pk = d_radio = d_len = d_info = None
+    d_cd = new((C_,), torch.uint8, zero=True)                             # mu-law (RTP PT 0) everywhere
+    d_pk = d_radio = d_pcm_in = d_slots = None
     if args.mode == "depayload":                                          # [F][C][180] ED-137 packets (header bytes arbitrary but PT 0)
-        d_pk = torch.empty((F_, C_, 180), dtype=torch.uint8, device="cuda")
+        d_pk = new((F_, C_, 180), torch.uint8)
         ctx.gen_uniform(d_pk, d_pk.numel(), seed=7, stream=hs)
         d_pk[:, :, 0] = 0x90
         d_pk[:, :, 1] = 0
-        d_radio = torch.ones((C_,), dtype=torch.uint8, device="cuda")
-        d_len = torch.empty((F_ * C_,), dtype=torch.int16, device="cuda")
-        d_info = torch.empty((F_ * C_,), dtype=torch.int64, device="cuda")
-    d_pcm_in = None
+        d_radio = new((C_,), torch.uint8)
+        d_radio.fill_(1)
     if args.mode == "encode":
-        d_pcm_in = torch.empty((F_, C_, n), dtype=torch.int16, device="cuda")
+        d_pcm_in = new((F_, C_, n), torch.int16)
         ctx.gen_uniform(d_pcm_in, d_pcm_in.numel() * 2, seed=11, stream=hs)
-        d_out = torch.empty_like(d_pl)
-    d_slots = None
     if args.mode == "rtp":                                                # [F][C][192] slots: size 180, PT 0, payload at +32
-        d_slots = torch.empty((F_, C_, 192), dtype=torch.uint8, device="cuda")
+        d_slots = new((F_, C_, 192), torch.uint8)
         ctx.gen_uniform(d_slots, d_slots.numel(), seed=7, stream=hs)
         d_slots[:, :, 0] = 180
         d_slots[:, :, 1:12] = 0
         d_slots[:, :, 12] = 0x90
         d_slots[:, :, 13] = 0
-        d_info = torch.empty((F_ * C_,), dtype=torch.int64, device="cuda")
     if args.mode == "packets":                                            # [F][C][180] ED-137 packets, PT 0, all full
-        d_slots = torch.empty((F_, C_, 180), dtype=torch.uint8, device="cuda")
+        d_slots = new((F_, C_, 180), torch.uint8)
         ctx.gen_uniform(d_slots, d_slots.numel(), seed=7, stream=hs)
         d_slots[:, :, 0] = 0x90
         d_slots[:, :, 1] = 0
-        d_info = torch.empty((F_ * C_,), dtype=torch.int64, device="cuda")
     if args.mode == "roundtrip":                                          # BASELINE configs[4]: mixed A-law / mu-law, D-speech
         d_cd[1::2] = 8
         # D-speech: two-tone + noise, amplitude 1000*(1 + c mod 30), encoded with the oracle's encoder.
@@ -193,11 +207,28 @@ def main():
         d_tile = torch.from_numpy(tile).cuda()
         d_pl.copy_(d_tile[:, torch.arange(C_, device="cuda") % tile_c, :])
         del d_tile
-        d_out = torch.empty_like(d_pl)
-        d_hold = torch.zeros((C_ * 4,), dtype=torch.int64, device="cuda")
-        ctx.hold_reset(d_hold, C_, stream=hs)
-    d_st = torch.zeros((F_ * C_ * 2,), dtype=torch.int64, device="cuda")   # igdsp_frame_stats[F][C]
-    d_pcm = torch.empty((F_, C_, n), dtype=torch.int16, device="cuda") if args.mode == "store" else None
+
+    # ---- outputs: everything a launch WRITES.  make_outputs(k) builds the set k spacers behind the inputs.
+    inputs_end = arena.cur if arena is not None else 0
+
+    def make_outputs(k=0):
+        if arena is not None:
+            arena.cur = inputs_end + k * spacer
+        O = {"st": new((F_ * C_ * 2,), torch.int64, zero=True)}          # igdsp_frame_stats[F][C]
+        if args.mode == "store":
+            O["pcm"] = new((F_, C_, n), torch.int16)
+        if args.mode in ("rtp", "packets", "depayload"):
+            O["info"] = new((F_ * C_,), torch.int64)
+        if args.mode == "depayload":
+            O["dense"] = new((F_, C_, n), torch.uint8)
+            O["len"] = new((F_ * C_,), torch.int16)
+        if args.mode in ("encode", "roundtrip"):
+            O["out"] = new((F_, C_, n), torch.uint8)
+        if args.mode == "roundtrip":
+            O["hold"] = new((C_ * 4,), torch.int64, zero=True)
+            ctx.hold_reset(O["hold"], C_, stream=hs)
+        return O
+
     # one pre-zeroed aggregate per step (896 B each): a launch ADDS into its aggregate, so nothing has to be cleared
     # between launches and, for N > 1, all-reduce k runs on the side stream on its own buffer while launch k + 1 runs
     n_steps_total = args.warmup + args.steps
@@ -205,23 +236,52 @@ def main():
     ev_k = [torch.cuda.Event() for _ in range(n_steps_total)] if world > 1 else []
     region = ctx.timer()                             # HIP events on the launch stream around the K timed launches
 
-    def launch(agg):
+    def launch(agg, O):
         if args.mode == "encode":
-            ctx.encode(d_pcm_in, d_cd, C_, F_, n, d_out, stream=hs)
+            ctx.encode(d_pcm_in, d_cd, C_, F_, n, O["out"], stream=hs)
         elif args.mode == "rtp":
-            ctx.decode_meter_rtp(d_slots, d_cd, C_, F_, d_st, info=d_info, agg=agg, rank=rank, stream=hs)
+            ctx.decode_meter_rtp(d_slots, d_cd, C_, F_, O["st"], info=O["info"], agg=agg, rank=rank, stream=hs)
         elif args.mode == "packets":
-            ctx.decode_meter_packets(d_slots, None, d_cd, C_, F_, 180, 20, d_st, info=d_info, agg=agg, rank=rank, stream=hs)
+            ctx.decode_meter_packets(d_slots, None, d_cd, C_, F_, 180, 20, O["st"], info=O["info"], agg=agg, rank=rank, stream=hs)
         elif args.mode == "depayload":
-            ctx.depayload(d_pk, None, d_radio, C_, F_, 180, n, d_pl, d_len, d_info, stream=hs)
+            ctx.depayload(d_pk, None, d_radio, C_, F_, 180, n, O["dense"], O["len"], O["info"], stream=hs)
         elif args.mode == "roundtrip":
-            ctx.roundtrip_peakhold(d_pl, d_cd, C_, F_, n, d_out, d_st, d_hold, stream=hs)
+            ctx.roundtrip_peakhold(d_pl, d_cd, C_, F_, n, O["out"], O["st"], O["hold"], stream=hs)
         else:
-            ctx.decode_meter(d_pl, d_cd, C_, F_, n, d_st, pcm=d_pcm, agg=None if args.no_agg else agg, rank=rank, stream=hs)
+            ctx.decode_meter(d_pl, d_cd, C_, F_, n, O["st"], pcm=O.get("pcm"), agg=None if args.no_agg else agg, rank=rank, stream=hs)
+
+    def gpu_ms(fn, reps):
+        t = ctx.timer()
+        t.start(hs)
+        for _ in range(reps):
+            fn()
+        t.stop(hs)
+        ms = t.elapsed_ms() / reps
+        t.close()
+        return ms
+
+    # clock pre-warm (not steps: no collective): repeat the launch until ~prewarm_ms of GPU time has passed
+    scratch_agg = torch.zeros((capi.AGG_WORDS,), dtype=torch.int64, device="cuda")
+    OUT = make_outputs(0)
+    spent = 0.0
+    while spent < args.prewarm_ms:
+        spent += 20 * gpu_ms(lambda: launch(scratch_agg, OUT), 20)
+
+    # output placement: candidate k sits k x --spacer-gib behind the inputs; the fastest (timed real launches) is kept
+    placement = None
+    if positions > 1:
+        times = []
+        for k in range(positions):
+            cand = OUT if k == 0 else make_outputs(k)
+            gpu_ms(lambda: launch(scratch_agg, cand), 3)
+            times.append(gpu_ms(lambda: launch(scratch_agg, cand), 10))
+        best = min(range(positions), key=lambda i: times[i])
+        OUT = make_outputs(best)
+        placement = {"positions_ms": [round(x, 4) for x in times], "spacer_GiB": args.spacer_gib, "chosen": best}
 
     def step(i: int):
         agg = agg_ring[i]
-        launch(agg)
+        launch(agg, OUT)
         if world > 1:                              # node-wide sum / peak: one 896-byte all-reduce per launch, side stream
             ev_k[i].record(main_s)
             with torch.cuda.stream(comm_s):
@@ -233,18 +293,10 @@ def main():
         with torch.cuda.stream(comm_s):
             dist.all_reduce(prime, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
-    # clock pre-warm (not steps: no aggregate, no collective): repeat the launch until ~prewarm_ms of GPU time has passed
-    if args.prewarm_ms > 0:
-        scratch_agg = torch.zeros((capi.AGG_WORDS,), dtype=torch.int64, device="cuda")
-        pre = ctx.timer()
-        spent = 0.0
-        while spent < args.prewarm_ms:
-            pre.start(hs)
-            for _ in range(20):
-                launch(scratch_agg)
-            pre.stop(hs)
-            spent += pre.elapsed_ms()
-        pre.close()
+    # the output set may have moved: warm the final configuration right in front of the warm-up steps
+    spent = 0.0
+    while spent < args.prewarm_ms:
+        spent += 20 * gpu_ms(lambda: launch(scratch_agg, OUT), 20)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -331,10 +383,10 @@ def main():
         fn.restype = CT.c_int
         fn.argtypes = [CT.c_void_p, CT.c_void_p, CT.c_size_t, CT.c_void_p, CT.c_void_p]
         for _ in range(3):
-            fn(ctx.h, d_pl.data_ptr(), d_pl.numel(), d_st.data_ptr(), hs)
+            fn(ctx.h, d_pl.data_ptr(), d_pl.numel(), OUT["st"].data_ptr(), hs)
         tm.start(hs)
         for _ in range(10):
-            fn(ctx.h, d_pl.data_ptr(), d_pl.numel(), d_st.data_ptr(), hs)
+            fn(ctx.h, d_pl.data_ptr(), d_pl.numel(), OUT["st"].data_ptr(), hs)
         tm.stop(hs)
         rw_ms = tm.elapsed_ms() / 10
         out["roofline"]["same_traffic_stream_ms"] = round(rw_ms, 4)
@@ -352,8 +404,8 @@ def main():
         except Exception:
             pass
 
-    if placement is not None:
-        out["config"]["placement_probe"] = placement
+    if placement:
+        out["config"]["output_placement"] = placement
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     elif rank == 0:

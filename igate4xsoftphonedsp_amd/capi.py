@@ -100,7 +100,7 @@ PROTOTYPES = [
     ("igdsp_timer_stop", _int, [_vp, _vp, _vp]),
     ("igdsp_timer_elapsed_ms", _int, [_vp, _vp, C.POINTER(C.c_float)]),
     ("igdsp_stream_read", _int, [_vp, _vp, C.c_size_t, _vp, _vp]),
-    ("igdsp_probe_placement", _int, [_vp, _vp, C.c_size_t, _u32, C.POINTER(C.c_float), _vp]),
+    ("igdsp_probe_placement", _int, [_vp, _vp, C.c_size_t, _vp, _u32, C.POINTER(C.c_float), _vp]),
     ("igdsp_set_variant", _int, [_vp, _int]),
 ]
 
@@ -266,9 +266,9 @@ class Context:
         self._ck(self.L.igdsp_sync(self.h, stream), "igdsp_sync")
 
     # -- timers
-    def probe_placement(self, buf, n_bytes, reps=10, stream=None) -> float:
+    def probe_placement(self, buf, n_bytes, out=None, reps=10, stream=None) -> float:
         ms = C.c_float(0)
-        self._ck(self.L.igdsp_probe_placement(self.h, _ptr(buf), n_bytes, reps, C.byref(ms), stream), "igdsp_probe_placement")
+        self._ck(self.L.igdsp_probe_placement(self.h, _ptr(buf), n_bytes, _ptr(out), reps, C.byref(ms), stream), "igdsp_probe_placement")
         return float(ms.value)
 
     def timer(self):

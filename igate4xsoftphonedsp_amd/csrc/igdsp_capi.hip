@@ -482,26 +482,31 @@ int igdsp_stream_read(igdsp_ctx *ctx, const void *d_src, size_t bytes, uint64_t 
     return IGDSP_OK;
 }
 
-int igdsp_probe_placement(igdsp_ctx *ctx, const void *d_buf, size_t bytes, uint32_t reps, float *ms_per_launch, void *stream)
+int igdsp_probe_placement(igdsp_ctx *ctx, const void *d_in, size_t bytes, void *d_out, uint32_t reps, float *ms_per_launch, void *stream)
 {
-    if (!ctx || !d_buf || !ms_per_launch || reps == 0 || bytes < 10240u || (reinterpret_cast<uintptr_t>(d_buf) & 15u)) return IGDSP_EINVAL;
+    if (!ctx || !d_in || !ms_per_launch || reps == 0 || bytes < 10240u || (reinterpret_cast<uintptr_t>(d_in) & 15u) ||
+        (reinterpret_cast<uintptr_t>(d_out) & 15u))
+        return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = pick(ctx, stream);
     void *scratch = nullptr;
     hipEvent_t a = nullptr, b = nullptr;
-    if (hipMalloc(&scratch, bytes / 10u + 4096u) != hipSuccess) return fail(ctx, IGDSP_ENOMEM, "probe scratch");
+    if (!d_out) {
+        if (hipMalloc(&scratch, bytes / 10u + 4096u) != hipSuccess) return fail(ctx, IGDSP_ENOMEM, "probe scratch");
+        d_out = scratch;
+    }
     hipError_t e = hipEventCreate(&a);
     if (e == hipSuccess) e = hipEventCreate(&b);
-    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx), d_buf, bytes, scratch, s);
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx), d_in, bytes, d_out, s);
     if (e == hipSuccess) e = hipEventRecord(a, s);
-    for (uint32_t i = 0; i < reps && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx), d_buf, bytes, scratch, s);
+    for (uint32_t i = 0; i < reps && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx), d_in, bytes, d_out, s);
     if (e == hipSuccess) e = hipEventRecord(b, s);
     if (e == hipSuccess) e = hipEventSynchronize(b);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
     if (a) (void)hipEventDestroy(a);
     if (b) (void)hipEventDestroy(b);
-    (void)hipFree(scratch);
+    if (scratch) (void)hipFree(scratch);
     if (e != hipSuccess) return fail(ctx, IGDSP_EDEVICE, "igdsp_probe_placement", e);
     *ms_per_launch = ms / (float)reps;
     return IGDSP_OK;

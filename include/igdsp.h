@@ -336,13 +336,16 @@ int igdsp_timer_elapsed_ms(igdsp_ctx *ctx, void *timer, float *ms); /* syncs on 
  * against besides the 8 TB/s nominal. */
 int igdsp_stream_read(igdsp_ctx *ctx, const void *d_src, size_t bytes, uint64_t *d_sink, void *stream);
 
-/* Placement probe.  On MI355X the rate of a read stream that is mixed with record writes depends on WHICH device
- * allocation holds the payload: identical allocations of one process fall into a fast and a slow class about 10 %
- * apart (the pure read rate is the same on both; tools/placement_probe.py).  This call times the bare
- * read + record-store stream (the meter kernel's traffic, no compute) over d_buf and returns the average launch time,
- * so a host can allocate its payload ring a few times at start-up and keep the fastest.  Synchronous: allocates a
- * scratch record buffer of bytes / 10, runs 3 + reps launches on `stream`, waits, frees. */
-int igdsp_probe_placement(igdsp_ctx *ctx, const void *d_buf, size_t bytes, uint32_t reps, float *ms_per_launch, void *stream);
+/* Placement probe.  On MI355X a stream that READS one large region of device memory and WRITES another runs ~13 %
+ * faster than one that reads and writes the same region (regions are tens of GiB; inside one 80 GiB allocation the
+ * bare read + record stream takes 0.218 ms across a region boundary and 0.252 ms within a region; the pure read rate
+ * is the same everywhere; tools/placement_map2.py).  This call times the bare read + record-store stream
+ * (the meter kernel's traffic, no compute) reading d_in and writing d_out (bytes / 10 are written; NULL = a scratch
+ * buffer allocated for the call), so a host can place its output buffers (records, PCM, re-encoded payload) a few
+ * candidate distances away from its payload ring at start-up and keep the fastest.  Synchronous: 3 + reps launches
+ * on `stream`, then waits. */
+int igdsp_probe_placement(igdsp_ctx *ctx, const void *d_in, size_t bytes, void *d_out, uint32_t reps,
+                          float *ms_per_launch, void *stream);
 
 /* Kernel variant selection for experiments (0 = default tuned path).
  *   1 = one wavefront per channel-frame (40 lanes x dword), the literal north_star mapping

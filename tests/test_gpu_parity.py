@@ -563,15 +563,20 @@ def test_half_million_channels_one_launch(ctx, orc):
 
 
 def test_probe_placement(ctx):
-    """igdsp_probe_placement: a positive per-launch time of the bare read + record stream; argument rules."""
+    """igdsp_probe_placement: a positive per-launch time of the bare read + record stream, with a scratch or a
+    caller-supplied record buffer; argument rules."""
     import ctypes as C
     torch = gu.torch_cuda()
     nbytes = 64 << 20
     buf = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
-    ms = ctx.probe_placement(buf, nbytes, reps=5)
-    assert 0.0 < ms < 5.0                                     # 64 MiB at >= 15 GB/s even on a throttled box
+    rec = torch.empty((nbytes // 10 + 4096,), dtype=torch.uint8, device="cuda")
+    for out in (None, rec):
+        ms = ctx.probe_placement(buf, nbytes, out=out, reps=5)
+        assert 0.0 < ms < 5.0                                 # 64 MiB at >= 15 GB/s even on a throttled box
     out = C.c_float(0)
-    assert ctx.L.igdsp_probe_placement(ctx.h, buf.data_ptr(), nbytes, 0, C.byref(out), None) == -22      # reps == 0
-    assert ctx.L.igdsp_probe_placement(ctx.h, buf.data_ptr() + 4, nbytes - 4, 5, C.byref(out), None) == -22   # alignment
-    assert ctx.L.igdsp_probe_placement(ctx.h, buf.data_ptr(), 100, 5, C.byref(out), None) == -22          # < one item
-    assert ctx.L.igdsp_probe_placement(ctx.h, None, nbytes, 5, C.byref(out), None) == -22
+    fn = ctx.L.igdsp_probe_placement
+    assert fn(ctx.h, buf.data_ptr(), nbytes, None, 0, C.byref(out), None) == -22                 # reps == 0
+    assert fn(ctx.h, buf.data_ptr() + 4, nbytes - 4, None, 5, C.byref(out), None) == -22         # alignment
+    assert fn(ctx.h, buf.data_ptr(), nbytes, rec.data_ptr() + 8, 5, C.byref(out), None) == -22   # alignment of the output
+    assert fn(ctx.h, buf.data_ptr(), 100, None, 5, C.byref(out), None) == -22                    # < one item
+    assert fn(ctx.h, None, nbytes, None, 5, C.byref(out), None) == -22
