@@ -44,13 +44,17 @@ def counters(sub):
 
 
 def durations(sub):
+    """durations [ns] of every KEY dispatch in chronological order"""
     f = one(f"{sub}/**/*kernel_trace.csv")
     d = []
     if f:
         for r in csv.DictReader(open(f)):
             if KEY in r["Kernel_Name"]:
-                d.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    return d
+                d.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    return [x[1] for x in sorted(d)]
+
+
+TIMED_STEPS = 20      # tools/profile.sh runs bench.py --steps 20: the LAST 20 dispatches of KEY are the timed region
 
 
 fetch, ff = counters("fetch")
@@ -84,7 +88,10 @@ for sub in ("sq", "sq2"):
         shutil.copy(f, os.path.join(dst, f"{tag}_pmc_{sub}.csv"))
 d = durations("stats")
 if d:
-    lines += [f"kernel-trace durations of `{KEY}` in the stats pass: n={len(d)} avg {sum(d) / len(d) / 1e3:.1f} us min {min(d) / 1e3:.1f} max {max(d) / 1e3:.1f}", ""]
+    t = d[-TIMED_STEPS:]
+    lines += [f"kernel-trace durations of `{KEY}` in the stats pass: all n={len(d)} dispatches (clock pre-warm, the "
+              f"output-placement trials on slower positions, warm-up, timed) avg {sum(d) / len(d) / 1e3:.1f} us min {min(d) / 1e3:.1f} max {max(d) / 1e3:.1f}; "
+              f"**the timed region (last {len(t)} dispatches) avg {sum(t) / len(t) / 1e3:.1f} us** min {min(t) / 1e3:.1f} max {max(t) / 1e3:.1f}", ""]
 bj = os.path.join(src, "bench_unprofiled.json")
 if os.path.exists(bj):
     txt = [l for l in open(bj).read().splitlines() if l.startswith("{")]
@@ -95,7 +102,8 @@ if os.path.exists(bj):
 lines += ["## Reading", "",
           "* `k_meter_chunk64` vs the two bare calibration kernels in the same stats pass: `k_stream_read` (read-only) and",
           "  `k_stream_rw` (this kernel's exact traffic: 10 KiB read + 1 KiB record store per super-chunk, no per-sample work).",
-          "  The meter kernel sits within ~10 % of `k_stream_rw`; the record stores (10 % of the bytes) cost ~25 % of the time.",
+          "  The meter kernel sits within ~5-10 % of `k_stream_rw`.  With the record buffer in another memory region than the",
+          "  payload (DESIGN.md 7) the record stores (10 % of the bytes) add ~12 % to the pure read time; in the same region ~25 %.",
           "* PMC traffic = 0.999 x algorithmic bytes: every payload byte crosses the fabric exactly once.",
           "* `SQ_LDS_BANK_CONFLICT = 0`: the replicated LUT layout is conflict-free on uniformly random codes.",
           "* A/B builds (`tools/ab.sh`, DESIGN.md 3.1): no LUT reads, -20 % VALU or no per-sample work at all change the time by < 4 %.", ""]
