@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="untimed launches of the step before the W warmup steps until this much GPU time has passed: the "
                          "GPU needs ~20 ms of load to reach its steady clocks (first 30 launches measure ~6 %% slow)")
-    ap.add_argument("--placement-positions", type=int, default=7,
+    ap.add_argument("--placement-positions", type=int, default=8,
                     help="candidate positions of the OUTPUT buffers, --spacer-gib apart; the fastest (timed real launches) is kept; 1 = off")
     ap.add_argument("--spacer-gib", type=float, default=12.0)
     return ap.parse_args()
