@@ -64,8 +64,10 @@ struct igdsp_ctx {
     // device-wide work counters: a ring so that launches in flight on different streams never share one
     uint32_t *d_queues = nullptr;                       // kQueueRing x 32 words (128 B apart)
     std::atomic<uint32_t> queue_turn{0};
-    bool global_queue = false;                          // IGDSP_GLOBAL_QUEUE=1: device-wide batched work queue (removes the
-                                                        // inter-CU tail; measured neutral on an idle MI355X)
+    bool global_queue = true;                           // device-wide batched work queue for k_meter_chunk64 (IGDSP_GLOBAL_QUEUE=0:
+                                                        // static per-block batches).  Removes the inter-CU tail: -2.5 % on the
+                                                        // headline launch once the outputs sit in another memory region than the
+                                                        // payload (tools/kernel_ab.py); neutral when they share a region.
 };
 namespace { constexpr uint32_t kQueueRing = 64; }
 
