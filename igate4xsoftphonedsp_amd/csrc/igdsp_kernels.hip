@@ -784,16 +784,60 @@ __device__ __forceinline__ void rtp_half(const uint2 *lut, uint2 *strip_half, ui
     }
 }
 
+// Work queue of a persistent block (the mechanism k_meter_chunk64 carries inline): a batch = W consecutive items; the
+// block's first batch is its blockIdx, later ones come from one device-wide counter (gq[0]; nullptr = static
+// blockIdx + j * G); the waves draw slots from an LDS counter and the wave that draws the first slot of local batch j
+// announces batch j + 1, so nobody waits on the device atomic.  gq[1] counts finished blocks; the last one re-arms.
+template <int W>
+struct BlockQueue { uint32_t next, batch[8], tag[8]; };
+
+template <int W>
+__device__ __forceinline__ void bq_init(BlockQueue<W> &q, uint32_t *gq, uint32_t G, uint32_t gb1)   // thread 0, before a barrier;
+{                                                                 // gb1 = atomicAdd(gq, 1u) issued earlier (its latency hides under the LUT fill)
+    q.next = (uint32_t)W;
+    for (int i = 0; i < 8; ++i) q.tag[i] = 0xFFFFFFFFu;
+    q.batch[0] = blockIdx.x; q.tag[0] = 0u;
+    q.batch[1] = gq ? gb1 + G : blockIdx.x + G; q.tag[1] = 1u;
+}
+
+template <int W>
+__device__ __forceinline__ uint32_t bq_grab(BlockQueue<W> &q, uint32_t *gq, uint32_t G, uint32_t lane)   // wave-uniform item id
+{
+    uint32_t v = 0;
+    if (lane == 0) {
+        const uint32_t s = atomicAdd(&q.next, 1u);
+        const uint32_t j = s / (uint32_t)W, w = s - j * (uint32_t)W;
+        if (w == 0u) {
+            const uint32_t nb = gq ? atomicAdd(gq, 1u) + G : blockIdx.x + (j + 1u) * G;
+            __hip_atomic_store(&q.batch[(j + 1u) & 7u], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&q.tag[(j + 1u) & 7u], j + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        while (__hip_atomic_load(&q.tag[j & 7u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j)
+            __builtin_amdgcn_s_sleep(2);                         // published by a wave of this block that never waits on us
+        v = __hip_atomic_load(&q.batch[j & 7u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * (uint32_t)W + w;
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+__device__ __forceinline__ void bq_finish(uint32_t *gq, uint32_t G)                     // all threads, end of the kernel
+{
+    if (gq == nullptr) return;
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(gq + 1, 1u) == G - 1u) { gq[0] = 0u; gq[1] = 0u; }
+}
+
 template <bool AGG, bool SLOT>
 __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     const uint8_t *__restrict__ slots, const uint16_t *__restrict__ sizes, const uint8_t *__restrict__ codec, uint32_t C,
     uint32_t n_frames, uint32_t stride, uint32_t hdr, igdsp_frame_stats *__restrict__ stats, igdsp_rtp_info *__restrict__ info,
-    igdsp_aggregate *agg, uint32_t rank)
+    igdsp_aggregate *agg, uint32_t rank, uint32_t *gqueue)
 {
     __shared__ uint2 lds[kLutEntries + kRtpWaves * kRtpStrip];
-    __shared__ uint32_t next_item;
+    __shared__ BlockQueue<kRtpWaves> bq;
+    uint32_t gb1 = 0;
+    if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);
     fill_lut(lds);
-    if (threadIdx.x == 0) next_item = kRtpWaves;
+    if (threadIdx.x == 0) bq_init(bq, gqueue, gridDim.x, gb1);
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -827,13 +871,9 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
 
     auto ld = [&](const uint8_t *b, uint32_t o) { return SLOT ? ld_stream(reinterpret_cast<const uint4 *>(b + o)) : ld16_dw(b + o); };
     auto fetch_pt = [&](uint32_t sidx) { return (uint32_t)codec[(sidx * (uint32_t)kSuperFrames + lane) % C]; };
-    auto grab = [&]() {
-        uint32_t k = 0;
-        if (lane == 0) k = atomicAdd(&next_item, 1u);
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-    };
+    auto grab = [&]() { return bq_grab(bq, gqueue, G, lane); };
 
-    uint32_t sidx = blockIdx.x + wave * G;
+    uint32_t sidx = blockIdx.x * (uint32_t)kRtpWaves + wave;     // batch blockIdx.x, slot = wave
     if (sidx < n_super) {
         uint4 X[kRtpHalfLoads], Y[kRtpHalfLoads];
         uint32_t cur_pt = fetch_pt(sidx);
@@ -844,9 +884,8 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
 #pragma unroll
             for (int j = 0; j < kRtpHalfLoads; ++j) Y[j] = ld(b0, roff1[j]);
         }
-        uint32_t k_next = grab();
+        uint32_t s_next = grab();
         for (;;) {
-            const uint32_t s_next = blockIdx.x + k_next * G;
             const bool has_next = s_next < n_super;
             const uint32_t s_load = has_next ? s_next : 0u;
             const uint32_t f0 = sidx * kSuperFrames;
@@ -865,7 +904,7 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
             if (!SLOT && sizes != nullptr) my_size = sizes[f0 + lane];
             rtp_half<SLOT>(lds, strip, X, lm0, pm, hs, off, lane, nbase, roff0);
             rtp_half<SLOT>(lds, strip + kRtpStrip / 2, Y, lm1, pm, hs, off, lane, nbase, roff1);
-            if (has_next) k_next = grab();
+            const uint32_t s_after = has_next ? grab() : 0xFFFFFFFFu;   // its LDS round trip hides under the fold below
             wave_lds_fence();
             {
                 const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kSlotPieces);   // 96-byte rows
@@ -916,9 +955,11 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
             wave_lds_fence();
             if (!has_next) break;
             sidx = s_next;
+            s_next = s_after;
             cur_pt = nxt_pt;
         }
     }
+    bq_finish(gqueue, G);
     if (AGG && agg != nullptr)
         agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kRtpWaves, a_sumsq, (uint64_t)a_frames * kFrame, a_frames,
                          a_sil, a_clip, a_bm, a_peak);
@@ -1900,11 +1941,11 @@ hipError_t launch_decode_meter_rtp(const LaunchCfg &cfg, const uint8_t *slots, c
     const uint32_t grid = blocks_for(n_frames / kSuperFrames, kRtpWaves, (uint32_t)cfg.compute_units);
     const dim3 blk(kRtpWaves * 64);
     if (stride == 0) {
-        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank);
-        else     hipLaunchKernelGGL((k_meter_rtp64<false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank);
+        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, cfg.gqueue);
+        else     hipLaunchKernelGGL((k_meter_rtp64<false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, cfg.gqueue);
     } else {
-        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank);
-        else     hipLaunchKernelGGL((k_meter_rtp64<false, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank);
+        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, cfg.gqueue);
+        else     hipLaunchKernelGGL((k_meter_rtp64<false, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, cfg.gqueue);
     }
     return hipGetLastError();
 }
