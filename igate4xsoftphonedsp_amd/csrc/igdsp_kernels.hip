@@ -1147,18 +1147,24 @@ __global__ __launch_bounds__(1024) void k_encode_v8_table(const int16_t *__restr
 // whole frames + groups, so no division runs inside the loop.
 template <int VARIANT>
 __global__ __launch_bounds__(1024) void k_encode_lut16(const int16_t *__restrict__ pcm, const uint8_t *__restrict__ codec,
-                                                       uint32_t C, uint32_t n, uint64_t n_groups, uint8_t *__restrict__ out)
+                                                       uint32_t C, uint32_t n, uint32_t n_groups, uint8_t *__restrict__ out,
+                                                       uint32_t *gqueue)
 {
+    constexpr int kW = 16;                                         // launched with 1024 threads
     __shared__ uint8_t tab[2 * 65536];
+    __shared__ BlockQueue<kW> bq;
+    uint32_t gb1 = 0;
+    if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);
     {
         const EncK ku = enc_consts<VARIANT>(false), ka = enc_consts<VARIANT>(true);
         for (uint32_t i = threadIdx.x; i < 2u * 65536u; i += blockDim.x)
             tab[i] = (uint8_t)enc_uni<VARIANT>((int)(int16_t)(i & 0xFFFFu), (i >> 16) ? ka : ku);
     }
+    if (threadIdx.x == 0) bq_init(bq, gqueue, gridDim.x, gb1);
     __syncthreads();
     const uint32_t gpf = n >> 3;                                   // 8-sample groups per frame
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    auto encode_group = [&](uint64_t gi, const uint4 d, uint32_t pt) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, G = gridDim.x;
+    auto encode_group = [&](uint32_t gi, const uint4 d, uint32_t pt) {
         const uint32_t law = pt == IGDSP_PT_PCMA ? 1u : 0u;        // becomes address byte 2: +64 KiB
         const uint32_t w[4] = {d.x, d.y, d.z, d.w};
         uint32_t r[8];
@@ -1173,52 +1179,53 @@ __global__ __launch_bounds__(1024) void k_encode_lut16(const int16_t *__restrict
         reinterpret_cast<uint2 *>(out)[gi] = o;
     };
     const uint4 *src = reinterpret_cast<const uint4 *>(pcm);
-    // A wave walks 8 KiB chunks (kP pieces of 64 x 16 B, contiguous); the waves of a block take neighbouring chunks.
-    // Piece j's register is reloaded from the wave's next chunk as soon as piece j is encoded.
+    // A wave takes 8 KiB chunks (kP pieces of 64 x 16 B, contiguous) from the block / device work queue (batches of 16
+    // neighbouring chunks); piece j's register is reloaded from the wave's next chunk as soon as piece j is encoded.
     constexpr int kP = 8;
     constexpr uint32_t kChunkGroups = 64u * kP;
-    const uint64_t n_chunks = n_groups / kChunkGroups;
-    const uint64_t n_waves = (uint64_t)gridDim.x * wpb;
-    uint64_t chunk = (uint64_t)blockIdx.x * wpb + wave;
-    if (chunk < n_chunks) {
-        // (channel, group-in-frame) of each piece, advanced by adds: one chunk step = step_c channels + step_r groups
-        const uint64_t step = n_waves * kChunkGroups;
-        const uint32_t step_r = (uint32_t)(step % gpf), step_c = (uint32_t)((step / gpf) % C);
-        const uint64_t g0 = chunk * kChunkGroups + lane;
-        uint32_t gin[kP], cc[kP];
-        gin[0] = (uint32_t)(g0 % gpf); cc[0] = (uint32_t)((g0 / gpf) % C);
+    const uint32_t n_chunks = n_groups / kChunkGroups;
+    // channel of piece j of a chunk = channel of its piece 0 advanced by 64 j groups: wave-uniform (frames, groups) steps
+    uint32_t d_r[kP], d_c[kP];
 #pragma unroll
-        for (int j = 1; j < kP; ++j) {
-            gin[j] = gin[0] + (64u * j) % gpf; cc[j] = cc[0] + ((64u * j) / gpf) % C;
-            if (gin[j] >= gpf) { gin[j] -= gpf; cc[j] += 1u; }
-            if (cc[j] >= C) cc[j] -= C;
+    for (int j = 0; j < kP; ++j) { d_r[j] = (64u * j) % gpf; d_c[j] = ((64u * j) / gpf) % C; }
+    auto channels_of = [&](uint32_t chunk, uint32_t (&cc)[kP]) {
+        const uint32_t g0 = chunk * kChunkGroups + lane, f = g0 / gpf, gin0 = g0 - f * gpf, c0 = f % C;
+#pragma unroll
+        for (int j = 0; j < kP; ++j) {
+            uint32_t gi = gin0 + d_r[j], c = c0 + d_c[j];
+            if (gi >= gpf) c += 1u;
+            if (c >= C) c -= C;
+            cc[j] = c;
         }
+    };
+    uint32_t chunk = blockIdx.x * (uint32_t)kW + wave;
+    if (chunk < n_chunks) {
         uint4 d[kP];
-        uint32_t pt[kP];
+        uint32_t pt[kP], cc[kP];
+        channels_of(chunk, cc);
 #pragma unroll
-        for (int j = 0; j < kP; ++j) { d[j] = ld_stream(src + (g0 + 64u * j)); pt[j] = codec[cc[j]]; }
+        for (int j = 0; j < kP; ++j) { d[j] = ld_stream(src + (chunk * kChunkGroups + lane + 64u * j)); pt[j] = codec[cc[j]]; }
+        uint32_t next = bq_grab(bq, gqueue, G, lane);
         for (;;) {
-            const uint64_t next = chunk + n_waves;
             const bool has_next = next < n_chunks;
-            const uint64_t gl = (has_next ? next : chunk) * kChunkGroups + lane;   // last round re-reads itself: loads stay unconditional
-            const uint64_t gs = chunk * kChunkGroups + lane;
+            const uint32_t nl = has_next ? next : chunk;           // last round re-reads itself: loads stay unconditional
+            const uint32_t gl = nl * kChunkGroups + lane, gs = chunk * kChunkGroups + lane;
+            channels_of(nl, cc);
 #pragma unroll
             for (int j = 0; j < kP; ++j) {
-                gin[j] += step_r; cc[j] += step_c;
-                if (gin[j] >= gpf) { gin[j] -= gpf; cc[j] += 1u; }
-                if (cc[j] >= C) cc[j] -= C;
                 encode_group(gs + 64u * j, d[j], pt[j]);
                 d[j] = ld_stream(src + (gl + 64u * j));
                 pt[j] = codec[cc[j]];
             }
             if (!has_next) break;
             chunk = next;
+            next = bq_grab(bq, gqueue, G, lane);
         }
     }
     // groups beyond the last whole chunk (< 512): plain grid-stride
-    for (uint64_t g = n_chunks * kChunkGroups + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups;
-         g += (uint64_t)gridDim.x * blockDim.x)
-        encode_group(g, src[g], codec[(uint32_t)((g / gpf) % C)]);
+    for (uint32_t g = n_chunks * kChunkGroups + blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x)
+        encode_group(g, src[g], codec[(g / gpf) % C]);
+    bq_finish(gqueue, G);
 }
 
 template <int VARIANT>
@@ -1969,11 +1976,11 @@ hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t
     const bool v8 = ((n & 7u) == 0u) && ((reinterpret_cast<uintptr_t>(pcm) & 15u) == 0u) &&
                     ((reinterpret_cast<uintptr_t>(out) & 7u) == 0u);
     const uint32_t cap = (uint32_t)cfg.compute_units * 8u;
-    if (v8 && n_samples >= (1u << 25)) {                        // large batches: full 16-bit table, one block per CU
-        const uint64_t groups = n_samples >> 3;
+    if (v8 && n_samples >= (1u << 25) && (n_samples >> 3) < 0xFFFF0000ull) {   // large batches: full 16-bit table, one block per CU (32-bit group ids)
+        const uint32_t groups = (uint32_t)(n_samples >> 3);    // 32-bit group ids (checked above)
         const uint32_t grid = blocks_for(groups, 1024, (uint32_t)cfg.compute_units);
-        if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_G191>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, groups, out);
-        else                           hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_SUN16>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, groups, out);
+        if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_G191>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, groups, out, cfg.gqueue);
+        else                           hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_SUN16>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, groups, out, cfg.gqueue);
     } else if (v8 && n_samples >= (1u << 22)) {                 // big batches: table-driven compressor, persistent blocks
         const uint64_t groups = n_samples >> 3;
         const uint32_t grid = blocks_for(groups, 1024, (uint32_t)cfg.compute_units * 2u);
