@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels", type=int, default=65536, help="channels PER GPU")
     ap.add_argument("--frames", type=int, default=128)
+    ap.add_argument("--total-channels", type=int, default=0,
+                    help="strong scaling: this many channels in total, split evenly over the ranks (SURVEY 8d: 524288 over 1/2/4/8 "
+                         "GPUs); overrides --channels and reports \"scaling\": \"strong\"")
     ap.add_argument("--mode", choices=["meter", "store", "roundtrip", "depayload", "rtp", "packets", "encode"], default="meter")
     ap.add_argument("--variant", type=int, default=0, help="0 tuned default, 1 wave-per-frame, 2 chunk32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -89,7 +92,18 @@ def cpu_baseline(seconds: float):
                   f"of the same D-uniform stream, x{repsn} passes, {cores} pthreads",
         "single_thread_value": round(samples / t1 / 1e6, 2),
         "reference_loop_byte_mean_value": round(samples / tb / 1e6, 2),
+        "cpu_model": _cpu_model(), "compiler_flags": "gcc -O2 -funsigned-char (oracle/Makefile; -O2 as the reference's .pro:88)",
     }
+
+
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -120,6 +134,10 @@ def main():
     if world > capi.AGG_MAX_RANKS:
         raise SystemExit("aggregate vector has 8 peak slots")
 
+    if args.total_channels:
+        if args.total_channels % (world * 64):
+            raise SystemExit("--total-channels must be a multiple of 64 x the number of ranks")
+        args.channels = args.total_channels // world
     C_, F_, n = args.channels, args.frames, N_SAMPLES
     C_total = C_ * world
     ctx = capi.Context(device=local, max_channels=1024)
@@ -343,7 +361,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.total_channels else "weak",
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
