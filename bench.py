@@ -60,8 +60,9 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="untimed launches of the step before the W warmup steps until this much GPU time has passed: the "
                          "GPU needs ~20 ms of load to reach its steady clocks (first 30 launches measure ~6 %% slow)")
-    ap.add_argument("--placement-positions", type=int, default=8,
-                    help="candidate positions of the OUTPUT buffers, --spacer-gib apart; the fastest (timed real launches) is kept; 1 = off")
+    ap.add_argument("--placement-positions", type=int, default=16,
+                    help="candidate positions of the OUTPUT buffers, --spacer-gib apart (as many as fit into 80 %% of the free "
+                         "device memory); the fastest (timed real launches) is kept; 1 = off")
     ap.add_argument("--spacer-gib", type=float, default=12.0)
     return ap.parse_args()
 
@@ -171,8 +172,13 @@ def main():
     spacer = int(args.spacer_gib * (1 << 30))
     arena = None
     if positions > 1 and F_ * C_ * n >= (1 << 24):
+        # inputs <= 3 x batch, outputs <= 3 x batch + slack, then one spacer per extra position.  One class of device
+        # memory can be a single run of ~96 GiB, so the search has to reach further than that when the memory is there.
+        fixed = F_ * C_ * n * 8
+        free_b = torch.cuda.mem_get_info()[0]
+        positions = max(1, min(positions, int((0.8 * free_b / max(1, world if args.one_gpu_rehearsal else 1) - fixed) // spacer)))
         try:
-            arena = Arena(F_ * C_ * n * 8 + positions * spacer)      # inputs <= 3 x batch, outputs <= 3 x batch, slack
+            arena = Arena(fixed + positions * spacer) if positions > 1 else None
         except RuntimeError:
             arena = None                                              # not enough free device memory: plain allocations
     if arena is None:

@@ -544,6 +544,16 @@ int igdsp_internal_stream_mix(igdsp_ctx *ctx, const void *d_src, void *d_dst, ui
     return IGDSP_OK;
 }
 
+// same, odd items write into a second window (d_dst2 addressed like d_dst) and, if d_src2 is given, read from a second one
+int igdsp_internal_stream_mix2(igdsp_ctx *ctx, const void *d_src, void *d_dst, void *d_dst2, uint32_t n_items, int r, int w, int waves, void *stream,
+                               const void *d_src2)
+{
+    if (!ctx || !d_src || !d_dst || !d_dst2 || (reinterpret_cast<uintptr_t>(d_src2) & 15u) || ((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(d_dst) | reinterpret_cast<uintptr_t>(d_dst2)) & 15u)) return IGDSP_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_stream_mix(cfg_of(ctx), d_src, d_dst, n_items, r, w, waves, pick(ctx, stream), d_dst2, d_src2));
+    return IGDSP_OK;
+}
+
 // Diagnostic-only (not in include/igdsp.h): cycle stamps of the chunk32 kernel, 8 x u64 per wavefront
 // {t_begin, t_lut_ready, t_end, sum load-wait, sum process, iterations, sum frame-reduce, xcc id}.
 int igdsp_internal_diag_chunk32(igdsp_ctx *ctx, const uint8_t *d_payload, const uint8_t *d_codec, uint32_t C, uint32_t F,

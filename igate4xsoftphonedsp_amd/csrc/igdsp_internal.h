@@ -50,7 +50,7 @@ hipError_t launch_depayload(const LaunchCfg &cfg, const uint8_t *packets, const 
 hipError_t launch_g726(const LaunchCfg &cfg, const uint8_t *in, uint8_t *out, uint64_t n_bytes, int mode, hipStream_t s);
 hipError_t launch_gen_uniform(uint8_t *out, uint64_t n_bytes, uint64_t seed, uint64_t first_byte, hipStream_t s);
 hipError_t launch_stream_rw(const LaunchCfg &cfg, const void *src, size_t bytes, void *dst, hipStream_t s);
-hipError_t launch_stream_mix(const LaunchCfg &cfg, const void *src, void *dst, uint32_t n_items, int r, int w, int waves, hipStream_t s);
+hipError_t launch_stream_mix(const LaunchCfg &cfg, const void *src, void *dst, uint32_t n_items, int r, int w, int waves, hipStream_t s, void *dst2 = nullptr, const void *src2 = nullptr);
 hipError_t launch_stream_read(const LaunchCfg &cfg, const void *src, size_t bytes, uint64_t *sink, hipStream_t s);
 
 }  // namespace igdsp

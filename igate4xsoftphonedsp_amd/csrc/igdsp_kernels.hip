@@ -458,6 +458,17 @@ constexpr int kStripEntries = kSuperFrames * kPiecesPerFrame;  // 640 x 8 B = 5 
 // eight more live registers per lane and run 12 waves (768 threads, up to 168 VGPRs) instead of spilling.
 template <bool STORE_PCM> struct ChunkGeom { static constexpr int kWaves = STORE_PCM ? 12 : kWavesPerBlock; };
 
+// Order in which batches of work items are visited: the two halves of the item range alternately, so that at any
+// moment the launch reads and WRITES in two distant places of every buffer.  Write streams spread over two classes of
+// device memory run 11-22 % faster on MI355X than the same stream into one class (tools/stream_calib2.py, DESIGN.md
+// 7); a caller gets that by letting a bulk output buffer straddle a class boundary.  A bijection on [0, nb); ids >=
+// nb (queue exhausted) are returned unchanged.
+__device__ __forceinline__ uint32_t spread_batch(uint32_t b, uint32_t nb)
+{
+    const uint32_t half = (nb + 1u) >> 1;
+    return b >= nb ? b : ((b & 1u) ? half + (b >> 1) : (b >> 1));
+}
+
 // DIAG: a separate diagnostic instantiation (never the shipped path) that stamps where a
 // wave's cycles go; the stamps leave only through `diag`, no output is computed from them.
 template <bool STORE_PCM, bool AGG, bool DIAG = false>
@@ -502,6 +513,7 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
         pm[j] = probe_mask(p - fr[j] * 10u);
     }
 
+    const uint32_t n_batches = (n_frames / kSuperFrames + (uint32_t)kWaves - 1u) / (uint32_t)kWaves;
     const uint32_t n_super = n_frames / kSuperFrames;             // the launcher hands over whole super-chunks only:
     const uint4 *src16 = reinterpret_cast<const uint4 *>(payload); // no tail predicate anywhere in the loop
 
@@ -529,12 +541,12 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
             }
             while (__hip_atomic_load(&q_tag[j % kRing], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j)
                 __builtin_amdgcn_s_sleep(2);                     // published by a wave of this block that never waits on us
-            v = __hip_atomic_load(&q_batch[j % kRing], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * (uint32_t)kWaves + w;
+            v = spread_batch(__hip_atomic_load(&q_batch[j % kRing], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), n_batches) * (uint32_t)kWaves + w;
         }
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     };
 
-    uint32_t sidx = blockIdx.x * (uint32_t)kWaves + wave;        // batch blockIdx.x, slot = wave
+    uint32_t sidx = spread_batch(blockIdx.x, n_batches) * (uint32_t)kWaves + wave;   // batch blockIdx.x, slot = wave
     if (sidx < n_super) {
         uint4 X[kLoadsPerChunk], Y[kLoadsPerChunk];
         uint32_t cur_pt = fetch_pt(sidx);          // issue order pt, X, Y — the same in the prologue and in the loop,
@@ -801,7 +813,7 @@ __device__ __forceinline__ void bq_init(BlockQueue<W> &q, uint32_t *gq, uint32_t
 }
 
 template <int W>
-__device__ __forceinline__ uint32_t bq_grab(BlockQueue<W> &q, uint32_t *gq, uint32_t G, uint32_t lane)   // wave-uniform item id
+__device__ __forceinline__ uint32_t bq_grab(BlockQueue<W> &q, uint32_t *gq, uint32_t G, uint32_t lane, uint32_t nb)   // wave-uniform item id; nb = number of batches
 {
     uint32_t v = 0;
     if (lane == 0) {
@@ -814,7 +826,7 @@ __device__ __forceinline__ uint32_t bq_grab(BlockQueue<W> &q, uint32_t *gq, uint
         }
         while (__hip_atomic_load(&q.tag[j & 7u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j)
             __builtin_amdgcn_s_sleep(2);                         // published by a wave of this block that never waits on us
-        v = __hip_atomic_load(&q.batch[j & 7u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * (uint32_t)W + w;
+        v = spread_batch(__hip_atomic_load(&q.batch[j & 7u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), nb) * (uint32_t)W + w;
     }
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
@@ -871,9 +883,10 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
 
     auto ld = [&](const uint8_t *b, uint32_t o) { return SLOT ? ld_stream(reinterpret_cast<const uint4 *>(b + o)) : ld16_dw(b + o); };
     auto fetch_pt = [&](uint32_t sidx) { return (uint32_t)codec[(sidx * (uint32_t)kSuperFrames + lane) % C]; };
-    auto grab = [&]() { return bq_grab(bq, gqueue, G, lane); };
+    const uint32_t n_batches = (n_super + (uint32_t)kRtpWaves - 1u) / (uint32_t)kRtpWaves;
+    auto grab = [&]() { return bq_grab(bq, gqueue, G, lane, n_batches); };
 
-    uint32_t sidx = blockIdx.x * (uint32_t)kRtpWaves + wave;     // batch blockIdx.x, slot = wave
+    uint32_t sidx = spread_batch(blockIdx.x, n_batches) * (uint32_t)kRtpWaves + wave;     // batch blockIdx.x, slot = wave
     if (sidx < n_super) {
         uint4 X[kRtpHalfLoads], Y[kRtpHalfLoads];
         uint32_t cur_pt = fetch_pt(sidx);
@@ -1198,14 +1211,15 @@ __global__ __launch_bounds__(1024) void k_encode_lut16(const int16_t *__restrict
             cc[j] = c;
         }
     };
-    uint32_t chunk = blockIdx.x * (uint32_t)kW + wave;
+    const uint32_t n_batches = (n_chunks + (uint32_t)kW - 1u) / (uint32_t)kW;
+    uint32_t chunk = spread_batch(blockIdx.x, n_batches) * (uint32_t)kW + wave;
     if (chunk < n_chunks) {
         uint4 d[kP];
         uint32_t pt[kP], cc[kP];
         channels_of(chunk, cc);
 #pragma unroll
         for (int j = 0; j < kP; ++j) { d[j] = ld_stream(src + (chunk * kChunkGroups + lane + 64u * j)); pt[j] = codec[cc[j]]; }
-        uint32_t next = bq_grab(bq, gqueue, G, lane);
+        uint32_t next = bq_grab(bq, gqueue, G, lane, n_batches);
         for (;;) {
             const bool has_next = next < n_chunks;
             const uint32_t nl = has_next ? next : chunk;           // last round re-reads itself: loads stay unconditional
@@ -1219,7 +1233,7 @@ __global__ __launch_bounds__(1024) void k_encode_lut16(const int16_t *__restrict
             }
             if (!has_next) break;
             chunk = next;
-            next = bq_grab(bq, gqueue, G, lane);
+            next = bq_grab(bq, gqueue, G, lane, n_batches);
         }
     }
     // groups beyond the last whole chunk (< 512): plain grid-stride
@@ -1867,21 +1881,22 @@ __global__ __launch_bounds__(kBlockThreads) void k_stream_rw(const uint4 *__rest
 // Calibration of read : write mixes: every wave reads R and writes W contiguous 1 KiB pieces per item (16 neighbouring
 // items per block), nothing else.  <0,W> is a pure write stream, <R,R> a copy, <10,1> the meter's mix.
 template <int R, int W>
-__global__ __launch_bounds__(kBlockThreads) void k_stream_mix(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n_items)
+__global__ __launch_bounds__(kBlockThreads) void k_stream_mix(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n_items, uint4 *dst2, const uint4 *src2)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     for (uint32_t b = blockIdx.x; b * wpb + wave < n_items; b += gridDim.x) {
         const uint32_t item = b * wpb + wave;
         uint4 acc = make_uint4(item, lane, 0u, 0u);
         if (R > 0) {
-            const uint4 *p = src + ((uint64_t)item * (uint32_t)(R * 64) + lane);
+            const uint4 *p = ((src2 != nullptr && (item & 1u)) ? src2 : src) + ((uint64_t)item * (uint32_t)(R * 64) + lane);
             uint4 v[R > 0 ? R : 1];
 #pragma unroll
             for (int j = 0; j < R; ++j) v[j] = ld_stream(p + j * 64);
 #pragma unroll
             for (int j = 0; j < R; ++j) { acc.x ^= v[j].x; acc.y ^= v[j].y; acc.z ^= v[j].z; acc.w ^= v[j].w; }
         }
-        uint4 *q = dst + ((uint64_t)item * (uint32_t)(W * 64) + lane);
+        // dst2 != nullptr: odd items write to the second window (calibration of writes spread over two memory classes)
+        uint4 *q = ((dst2 != nullptr && (item & 1u)) ? dst2 : dst) + ((uint64_t)item * (uint32_t)(W * 64) + lane);
 #pragma unroll
         for (int j = 0; j < W; ++j) q[j * 64] = acc;
     }
@@ -2080,13 +2095,13 @@ hipError_t launch_stream_rw(const LaunchCfg &cfg, const void *src, size_t bytes,
     return hipGetLastError();
 }
 
-hipError_t launch_stream_mix(const LaunchCfg &cfg, const void *src, void *dst, uint32_t n_items, int r, int w, int waves, hipStream_t s)
+hipError_t launch_stream_mix(const LaunchCfg &cfg, const void *src, void *dst, uint32_t n_items, int r, int w, int waves, hipStream_t s, void *dst2, const void *src2)
 {
     if (waves < 1 || waves > 16) return hipErrorInvalidValue;
     const dim3 g(cfg.compute_units), b(waves * 64);
     const uint4 *sp = reinterpret_cast<const uint4 *>(src);
     uint4 *dp = reinterpret_cast<uint4 *>(dst);
-#define IGDSP_MIX(R, W) if (r == R && w == W) { hipLaunchKernelGGL((k_stream_mix<R, W>), g, b, 0, s, sp, dp, n_items); return hipGetLastError(); }
+#define IGDSP_MIX(R, W) if (r == R && w == W) { hipLaunchKernelGGL((k_stream_mix<R, W>), g, b, 0, s, sp, dp, n_items, reinterpret_cast<uint4 *>(dst2), reinterpret_cast<const uint4 *>(src2)); return hipGetLastError(); }
     IGDSP_MIX(0, 8) IGDSP_MIX(8, 8) IGDSP_MIX(8, 4) IGDSP_MIX(4, 8) IGDSP_MIX(10, 1) IGDSP_MIX(10, 0) IGDSP_MIX(8, 1) IGDSP_MIX(8, 2) IGDSP_MIX(20, 2) IGDSP_MIX(5, 1)
 #undef IGDSP_MIX
     return hipErrorInvalidValue;

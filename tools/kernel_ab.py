@@ -21,7 +21,7 @@ def main():
     del os.environ["IGDSP_GLOBAL_QUEUE"]
     C_, F_, n = 65536, 128, 160
     nbytes = C_ * F_ * n
-    arena = torch.empty((nbytes + (80 << 30),), dtype=torch.uint8, device="cuda")
+    arena = torch.empty((nbytes + (124 << 30),), dtype=torch.uint8, device="cuda")
     pl = arena[:nbytes]
     ctx.gen_uniform(pl, nbytes, seed=0x20241218)
     cd = torch.zeros((C_,), dtype=torch.uint8, device="cuda")
@@ -42,7 +42,7 @@ def main():
 
     # pick the record position (every 12 GiB) with the fastest bare stream
     best = None
-    for k in range(7):
+    for k in range(11):
         off = nbytes + (k * 12 << 30)
         off = (off + 4095) & ~4095
         st = arena[off:off + F_ * C_ * 16]
