@@ -313,11 +313,18 @@ __device__ __forceinline__ uint2 lut_at(const uint2 *lut, uint32_t t, uint32_t o
     return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(lut) + addr);
 }
 
+typedef short v2i16 __attribute__((ext_vector_type(2)));
+
+// two magnitudes -> one dword of signed int16 PCM (codes k and k + 1 of word w; a code is negative iff its bit 7 is
+// clear).  Packed 16-bit math: one v_perm puts the two inverted sign bits at bits 15 / 31, a packed arithmetic shift
+// turns them into 0x0000 / 0xFFFF masks m, and (p ^ m) - m negates the selected halves: 5 VALU per PAIR.
 __device__ __forceinline__ uint32_t pack_pcm(uint32_t w, uint32_t k, uint32_t ax0, uint32_t ax1)
 {
-    const int x0 = (w & (0x80u << (8u * k))) ? (int)ax0 : -(int)ax0;
-    const int x1 = (w & (0x8000u << (8u * k))) ? (int)ax1 : -(int)ax1;
-    return ((uint32_t)x0 & 0xFFFFu) | ((uint32_t)x1 << 16);
+    const uint32_t sb = __builtin_amdgcn_perm(~w, 0u, k == 0u ? 0x050C040Cu : 0x070C060Cu);
+    const v2i16 m = __builtin_bit_cast(v2i16, sb) >> (v2i16)(15);
+    const uint32_t p = ax0 | (ax1 << 16);
+    const v2i16 r = __builtin_bit_cast(v2i16, p ^ __builtin_bit_cast(uint32_t, m)) - m;
+    return __builtin_bit_cast(uint32_t, r);
 }
 
 __device__ __forceinline__ void wave_lds_fence()
