@@ -266,6 +266,31 @@ def test_roundtrip_peakhold_vs_oracle(ctx, orc, variant, F_):
     assert np.array_equal(eout, exp)
 
 
+@pytest.mark.parametrize("variant", [capi.ENC_SUN16, capi.ENC_G191])
+def test_roundtrip_every_code_as_the_peak(ctx, orc, variant):
+    """Fused round trip on frames that are one code repeated (every code x both laws) and on uniform random codes: the
+    kernel derives the frame peak from max (|x|/4)^2 with a float square root, so every one of the 256 magnitudes has to
+    come back exactly; codes, records and hold must equal the oracle's."""
+    torch = gu.torch_cuda()
+    C_, n = 512, 160
+    codec = np.where(np.arange(C_) >= 256, 8, 0).astype(np.uint8)
+    const = np.repeat((np.arange(C_) & 255).astype(np.uint8)[None, :, None], n, axis=2)          # [1][C][n]
+    payload = np.concatenate([const, orc.gen_uniform(3 * C_ * n, seed=5).reshape(3, C_, n)], axis=0)
+    F_ = payload.shape[0]
+    d_out, d_st, d_hold = gu.dev_zeros(F_ * C_ * n, 0xEE), gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.to_dev(gu.new_hold(C_))
+    ctx.roundtrip_peakhold(gu.to_dev(payload), gu.to_dev(codec), C_, F_, n, d_out, d_st, d_hold, variant=variant)
+    torch.cuda.synchronize()
+    eout, est, ehold = orc.roundtrip_peakhold(payload, codec, gu.new_hold(C_).view(orc.CHAN_HOLD), variant=variant)
+    gst = gu.to_host(d_st, capi.FRAME_STATS, (F_, C_))
+    assert np.array_equal(gst["peak"], est["peak"])
+    assert len(np.unique(est["peak"][0])) >= 240          # 128 + 128 magnitudes, a few shared by the two laws
+    gu.assert_stats_equal(gst, est, n=n)
+    assert np.array_equal(gu.to_host(d_out, np.uint8, (F_, C_, n)), eout)
+    ghold = gu.to_host(d_hold, capi.CHAN_HOLD)
+    for f in capi.CHAN_HOLD.names:
+        assert np.array_equal(ghold[f], ehold[f]), f
+
+
 def test_hold_update_and_reset(ctx, orc):
     torch = gu.torch_cuda()
     C_, F_, n = 300, 9, 160
