@@ -1900,7 +1900,8 @@ template <int R, int W>
 __global__ __launch_bounds__(kBlockThreads) void k_stream_mix(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n_items, uint4 *dst2, const uint4 *src2)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    for (uint32_t b = blockIdx.x; b * wpb + wave < n_items; b += gridDim.x) {
+    const uint32_t n_real = n_items & 0x7FFFFFFFu;      // bit 31 of n_items selects the half-line write pattern
+    for (uint32_t b = blockIdx.x; b * wpb + wave < n_real; b += gridDim.x) {
         const uint32_t item = b * wpb + wave;
         uint4 acc = make_uint4(item, lane, 0u, 0u);
         if (R > 0) {
@@ -1913,8 +1914,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_stream_mix(const uint4 *__res
         }
         // dst2 != nullptr: odd items write to the second window (calibration of writes spread over two memory classes)
         uint4 *q = ((dst2 != nullptr && (item & 1u)) ? dst2 : dst) + ((uint64_t)item * (uint32_t)(W * 64) + lane);
+        if (n_items & 0x80000000u) {
+            // calibration of the PCM-store write pattern: a pair of store instructions fills 2 KiB, each instruction writing
+            // 64-byte segments at 128-byte stride (the quad-regrouped stores of process_half<true>)
+            uint4 *qb = q - lane;
 #pragma unroll
-        for (int j = 0; j < W; ++j) q[j * 64] = acc;
+            for (int j = 0; j < W; ++j) qb[(j >> 1) * 128 + (lane >> 2) * 8 + (j & 1) * 4 + (lane & 3)] = acc;
+        } else {
+#pragma unroll
+            for (int j = 0; j < W; ++j) q[j * 64] = acc;
+        }
     }
 }
 

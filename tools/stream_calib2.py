@@ -41,6 +41,18 @@ def main():
             ms = tm.elapsed_ms() / 20
             res.append((ms, n_items * (r + w) * 1024 / ms / 1e6))
         print(f"read{r}:write{w}  writes in one class {res[0][0]:.4f} ms {res[0][1]:.0f} GB/s | spread over two classes {res[1][0]:.4f} ms {res[1][1]:.0f} GB/s")
+    # write pattern of the PCM store (64-byte segments at 128-byte stride, pairs of instructions) vs full 1 KiB per instruction
+    for r, w in [(4, 8), (0, 8)]:
+        for name, flag in (("1 KiB per store instruction", 0), ("64 B segments at 128 B stride", 0x80000000)):
+            p1, p2 = arena.data_ptr() + a, arena.data_ptr() + (b if b is not None else a)
+            for _ in range(3):
+                fn(ctx.h, src.data_ptr(), p1, p2, 131072 | flag, r, w, 16, None, None)
+            tm.start(None)
+            for _ in range(20):
+                fn(ctx.h, src.data_ptr(), p1, p2, 131072 | flag, r, w, 16, None, None)
+            tm.stop(None)
+            ms = tm.elapsed_ms() / 20
+            print(f"read{r}:write{w} spread, {name}: {ms:.4f} ms {131072 * (r + w) * 1024 / ms / 1e6:.0f} GB/s")
     # reads spread over two classes (src + window a), records into the third (b): the meter's 10:1 mix
     if b is not None:
         for name, s2 in (("reads from one class", None), ("reads spread over two classes", arena.data_ptr() + a)):
