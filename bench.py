@@ -13,6 +13,13 @@ across ranks (weak scaling: 65 536 ch per GPU; N = 8 is BASELINE configs[3], 524
 with ONE 896-byte RCCL all-reduce per launch for the node-wide sum-of-squares / peak,
 issued on a side stream behind the kernel's event.
 
+Before the W warm-up steps the bench (i) repeats the launch for ~60 ms so the clocks settle, and (ii) decides where the
+OUTPUT buffers live: inputs sit at the start of one device arena, the outputs are tried at up to 16 offsets 12 GiB apart
+(and, for modes with a bulk output, across a boundary between two classes of device memory) and the fastest placement
+by timed real launches is kept — on MI355X a launch that reads one class of device memory and writes another is ~13 %
+faster than one that reads and writes the same class (`--placement-positions 1 --prewarm-ms 0` turns
+both off; the choice is reported in config.output_placement).  None of this is inside a step.
+
 Rank 0 prints ONE JSON line; `roofline` is measured live with one pair of HIP events on the launch
 stream around the K timed launches (average launch duration = elapsed / K), `cpu_baseline` is the CPU oracle timed on this box's host cores (N = 1 only).
 """
