@@ -90,6 +90,7 @@ PROTOTYPES = [
     ("igdsp_gen_uniform", _int, [_vp, _vp, _u64, _u64, _u64, _vp]),
     ("igdsp_dev_alloc", _int, [_vp, C.POINTER(_vp), C.c_size_t]),
     ("igdsp_dev_free", _int, [_vp, _vp]),
+    ("igdsp_dev_alloc_far", _int, [_vp, C.POINTER(_vp), C.c_size_t, _vp, C.c_size_t, _u32, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("igdsp_copy_h2d", _int, [_vp, _vp, _vp, C.c_size_t]),
     ("igdsp_copy_d2h", _int, [_vp, _vp, _vp, C.c_size_t]),
     ("igdsp_dev_memset", _int, [_vp, _vp, _int, C.c_size_t]),

@@ -318,6 +318,13 @@ int igdsp_gen_uniform(igdsp_ctx *ctx, uint8_t *d_out, uint64_t n_bytes,
  * where a stream is given. */
 int igdsp_dev_alloc(igdsp_ctx *ctx, void **d_ptr, size_t bytes);
 int igdsp_dev_free(igdsp_ctx *ctx, void *d_ptr);
+/* Allocate an OUTPUT buffer in another class of device memory than the input it will be written from (see
+ * igdsp_probe_placement): tries up to max_tries positions, each a further spacer_bytes (0 = 12 GiB) of temporary
+ * allocation away, times the bare read(d_in) + write(candidate) stream for each, keeps the fastest candidate, frees the
+ * rest and the spacers.  Stops early once a candidate is >= 8 % faster than the first.  ms_first / ms_kept (optional)
+ * return the probe times of the plain first allocation and of the one kept.  Synchronous; start-up use only. */
+int igdsp_dev_alloc_far(igdsp_ctx *ctx, void **d_ptr, size_t bytes, const void *d_in, size_t in_bytes,
+                        uint32_t max_tries, size_t spacer_bytes, float *ms_first, float *ms_kept);
 int igdsp_copy_h2d(igdsp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int igdsp_copy_d2h(igdsp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int igdsp_dev_memset(igdsp_ctx *ctx, void *d_ptr, int value, size_t bytes);

@@ -605,3 +605,23 @@ def test_probe_placement(ctx):
     assert fn(ctx.h, buf.data_ptr(), nbytes, rec.data_ptr() + 8, 5, C.byref(out), None) == -22   # alignment of the output
     assert fn(ctx.h, buf.data_ptr(), 100, None, 5, C.byref(out), None) == -22                    # < one item
     assert fn(ctx.h, None, nbytes, None, 5, C.byref(out), None) == -22
+
+
+def test_dev_alloc_far(ctx):
+    """igdsp_dev_alloc_far: returns a usable output buffer whose probe time is never worse than the plain first
+    allocation's (on a box with room it is ~10 % better); argument rules."""
+    import ctypes as C
+    torch = gu.torch_cuda()
+    nbytes = 256 << 20
+    src = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
+    ptr, t0, t1 = C.c_void_p(), C.c_float(0), C.c_float(0)
+    fn = ctx.L.igdsp_dev_alloc_far
+    rc = fn(ctx.h, C.byref(ptr), 64 << 20, src.data_ptr(), nbytes, 12, 8 << 30, C.byref(t0), C.byref(t1))
+    assert rc == 0 and ptr.value
+    assert 0 < t1.value <= t0.value * 1.0001
+    assert ctx.L.igdsp_dev_memset(ctx.h, ptr, 0x5A, 64 << 20) == 0             # the buffer is real
+    torch.cuda.synchronize()
+    assert ctx.L.igdsp_dev_free(ctx.h, ptr) == 0
+    assert fn(ctx.h, C.byref(ptr), 0, src.data_ptr(), nbytes, 4, 0, None, None) == -22
+    assert fn(ctx.h, C.byref(ptr), 1 << 20, None, nbytes, 4, 0, None, None) == -22
+    assert fn(ctx.h, C.byref(ptr), 1 << 20, src.data_ptr(), nbytes, 0, 0, None, None) == -22
