@@ -539,7 +539,8 @@ int igdsp_internal_stream_rw(igdsp_ctx *ctx, const void *d_src, size_t bytes, vo
 // (pairs built: 0:8, 8:8, 8:4, 4:8, 10:1, 10:0, 8:1, 8:2, 20:2, 5:1; `waves` per block 1..16); src needs n_items * r KiB, dst n_items * w KiB.
 int igdsp_internal_stream_mix(igdsp_ctx *ctx, const void *d_src, void *d_dst, uint32_t n_items, int r, int w, int waves, void *stream)
 {
-    if (!ctx || !d_src || !d_dst || (reinterpret_cast<uintptr_t>(d_src) & 15u) || (reinterpret_cast<uintptr_t>(d_dst) & 15u)) return IGDSP_EINVAL;
+    // the source may be only dword aligned: that is what the calibration of misaligned 16-byte loads needs
+    if (!ctx || !d_src || !d_dst || (reinterpret_cast<uintptr_t>(d_src) & 3u) || (reinterpret_cast<uintptr_t>(d_dst) & 15u)) return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_stream_mix(cfg_of(ctx), d_src, d_dst, n_items, r, w, waves, pick(ctx, stream)));
     return IGDSP_OK;

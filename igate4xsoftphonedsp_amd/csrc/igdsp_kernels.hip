@@ -748,12 +748,13 @@ constexpr int kRtpHalfLoads = kSlotPieces * kChunkFrames / 64;     // 6 loads pe
 constexpr int kRtpStrip = kSuperFrames * kSlotPieces;              // 768 entries = 6 KiB per wave
 constexpr int kRtpWaves = 12;                                      // 64 KiB LUT + 72 KiB strips
 
-// 16 bytes at dword (not 16-byte) alignment: gfx950 global loads only need dword alignment for dwordx4
+// 16 bytes at dword (not 16-byte) alignment: gfx950 global loads only need dword alignment for dwordx4 (measured < 1 %
+// slower than aligned ones in a bare stream, tools/misaligned_loads.py).  Nontemporal like every other streaming load here.
+typedef uint32_t u32x4_a4_t __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ uint4 ld16_dw(const uint8_t *p)
 {
-    struct __attribute__((packed, aligned(4))) Q { uint32_t a, b, c, d; };
-    const Q q = *reinterpret_cast<const Q *>(p);
-    return make_uint4(q.a, q.b, q.c, q.d);
+    const u32x4_a4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4_t *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 // SLOT = true : 192-byte slots (size word + pad + packet at +12), every piece 16-byte aligned.
