@@ -375,10 +375,14 @@ __device__ __forceinline__ uint4 pack_stats160(uint64_t s, uint32_t peak, uint32
 // units of 8 samples: unit u+1's eight ds_read_b64 are in flight while unit u is folded, so a wave
 // hides most LDS latency by itself (at most 16 LDS reads outstanding = the lgkmcnt limit).
 // ----------------------------------------------------------------------------
+#ifndef IGDSP_STORE_XPOSE
+#define IGDSP_STORE_XPOSE 1
+#endif
 template <bool STORE_PCM>
 __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half, uint4 (&d)[kLoadsPerChunk],
                                              const uint32_t (&lm)[kLoadsPerChunk], const uint32_t (&pm)[kLoadsPerChunk],
-                                             const uint32_t off, const uint32_t lane, uint4 *pcm_half, const uint4 *refill)
+                                             const uint32_t off, const uint32_t lane, uint4 *pcm_half, const uint4 *refill,
+                                             uint4 *xpose = nullptr)
 {
     // `refill` = this lane's first piece of the NEXT super-chunk's same half: piece j's register is
     // reloaded the moment piece j has been folded, so the five loads trickle out evenly and get
@@ -421,6 +425,18 @@ __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half
                 // bytes per quad (lane i of the quad stores 16-byte chunk i, the second store chunk 4 + i)
                 // instead of 16-byte pieces at 32-byte stride.  Plain (cached) stores: L2 merges the two halves
                 // of a line; the nontemporal form measured 18 % slower on this pattern.
+#if IGDSP_STORE_XPOSE
+                // transposition through a per-wave 2 KiB LDS scratch: lane l parks its 32 bytes at l * 32, then reads back
+                // bytes [16 l, 16 l + 16) of each KiB, so both store instructions write 1 KiB contiguous (whole lines)
+                xpose[2u * lane] = make_uint4(o[0], o[1], o[2], o[3]);
+                xpose[2u * lane + 1u] = make_uint4(o[4], o[5], o[6], o[7]);
+                wave_lds_fence();
+                const uint4 v0 = xpose[lane], v1 = xpose[64u + lane];
+                wave_lds_fence();
+                uint4 *op = pcm_half + ((uint32_t)j * 128u + lane);
+                op[0] = v0;
+                op[64] = v1;
+#else
                 const bool odd = (lane & 1u) != 0u;
                 uint32_t s1[4], s2[4];
 #pragma unroll
@@ -435,6 +451,7 @@ __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half
                 uint4 *op = pcm_half + ((uint32_t)j * 128u + (lane >> 2) * 8u + (lane & 3u));
                 op[0] = make_uint4(s1[0], s1[1], s1[2], s1[3]);
                 op[4] = make_uint4(s2[0], s2[1], s2[2], s2[3]);
+#endif
             }
             d[j] = ld_stream(refill + j * 64);
             sum = 0; peak = 0; bsum = 0;
@@ -485,7 +502,7 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
     uint64_t *__restrict__ diag = nullptr, uint32_t *__restrict__ gqueue = nullptr)
 {
     constexpr int kWaves = ChunkGeom<STORE_PCM>::kWaves;
-    __shared__ uint2 lds[kLutEntries + kWaves * kStripEntries];   // 64 KiB LUT + 5 KiB strip per wave
+    __shared__ uint2 lds[kLutEntries + kWaves * kStripEntries + (STORE_PCM ? kWaves * 256 : 0)];   // 64 KiB LUT + 5 KiB strip per wave (+ 2 KiB PCM transposition scratch)
     // Work queue.  A *batch* = kWaves consecutive super-chunks.  The block's first batch is static (its
     // blockIdx); further batches come from ONE device-wide counter (gqueue[0], one atomic per batch, i.e.
     // per ~160 KiB of input), so fast CUs take more and the launch has no inter-CU tail.  Inside the block
@@ -510,6 +527,7 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint2 *strip = lds + kLutEntries + wave * kStripEntries;
+    uint4 *xpose = STORE_PCM ? reinterpret_cast<uint4 *>(lds + kLutEntries + kWaves * kStripEntries + wave * 256) : nullptr;
     const uint32_t off = (lane & 31u) * 8u;
 
     uint32_t fr[kLoadsPerChunk], pm[kLoadsPerChunk];   // frame-in-half / probe mask of this lane's five pieces per half
@@ -581,9 +599,9 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
             const uint4 *nsrc = src16 + (s_load * (uint32_t)kStripEntries + lane);
             const uint32_t nxt_pt = fetch_pt(s_load);
             if (DIAG) d_b = now_cycles();
-            process_half<STORE_PCM>(lds, strip, X, lm0, pm, off, lane, pcm16, nsrc);
+            process_half<STORE_PCM>(lds, strip, X, lm0, pm, off, lane, pcm16, nsrc, xpose);
             if (DIAG) d_c = now_cycles();
-            process_half<STORE_PCM>(lds, strip + kPiecesPerChunk, Y, lm1, pm, off, lane, pcm16 + 2 * kPiecesPerChunk, nsrc + kPiecesPerChunk);
+            process_half<STORE_PCM>(lds, strip + kPiecesPerChunk, Y, lm1, pm, off, lane, pcm16 + 2 * kPiecesPerChunk, nsrc + kPiecesPerChunk, xpose);
             if (DIAG) d_d = now_cycles();
             const uint32_t s_after = has_next ? grab() : 0xFFFFFFFFu;   // its LDS round trip hides under the frame fold below
 
