@@ -1592,12 +1592,13 @@ __device__ __forceinline__ FrameHdr parse_rtp(const uint8_t *pkt, uint32_t size,
 // piece), writes len / info coalesced and publishes the payload length; each payload piece then masks and stores
 // itself into the dense output (one contiguous run per store instruction).
 constexpr int kDpWaves = 4;
-__global__ __launch_bounds__(kDpWaves * 64, 4) void k_depayload64(const uint8_t *__restrict__ packets, const uint16_t *__restrict__ sizes,
+__global__ __launch_bounds__(kDpWaves * 64, 3) void k_depayload64(const uint8_t *__restrict__ packets, const uint16_t *__restrict__ sizes,
                                                                const uint8_t *__restrict__ radio, uint32_t C, uint32_t n_frames,
                                                                uint32_t stride, uint8_t *__restrict__ payload,
                                                                uint16_t *__restrict__ len, igdsp_rtp_info *__restrict__ info)
 {
     __shared__ uint4 hdrs[kDpWaves][64];          // per packet {bytes 0-3, -, ext word, ED-137 word}; .y reused for the parsed length
+    __shared__ uint4 xp[kDpWaves][kSuperFrames * kPiecesPerFrame];   // 10 KiB per wave: the dense output block, for whole-line stores
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint4 *hw = hdrs[wave];
     const uint32_t n_super = n_frames / kSuperFrames;
@@ -1651,9 +1652,13 @@ __global__ __launch_bounds__(kDpWaves * 64, 4) void k_depayload64(const uint8_t 
                     const uint32_t bits = 8u * (nb > 4u * k ? min(nb - 4u * k, 4u) : 0u);
                     x[k] &= (uint32_t)((1ull << bits) - 1ull);
                 }
-                ob[fr * (uint32_t)kPiecesPerFrame + (q - 2u)] = make_uint4(x[0], x[1], x[2], x[3]);
+                xp[wave][fr * (uint32_t)kPiecesPerFrame + (q - 2u)] = make_uint4(x[0], x[1], x[2], x[3]);
             }
         }
+        wave_lds_fence();
+        // the block is complete in LDS in output order: ten stores of 1 KiB of whole lines each
+#pragma unroll
+        for (int j = 0; j < kPiecesPerFrame; ++j) ob[(uint32_t)j * 64u + lane] = xp[wave][(uint32_t)j * 64u + lane];
         wave_lds_fence();
     }
 }
