@@ -15,3 +15,4 @@ for k, c in agg.items():
     if "igdsp" in k and "gen_uniform" not in k and "stream" not in k:
         print(k, {n: round(sum(v) / len(v)) for n, v in c.items()}, "dispatches", len(next(iter(c.values()))))
 PY
+# note: rocprofv3 aborted (signal 6) on a pass that mixed TA_* and TCC_* counters; keep a pass to one block's counters (SQ_*, or TCC_*, ...)
