@@ -457,6 +457,25 @@ int igdsp_decode_meter_packets(igdsp_ctx *ctx, const uint8_t *d_packets, const u
     return IGDSP_OK;
 }
 
+int igdsp_decode_meter_packets_mixed(igdsp_ctx *ctx, const uint8_t *d_packets, const uint16_t *d_sizes, const uint8_t *d_codec,
+                                     const uint8_t *d_radio, uint32_t C, uint32_t F, uint32_t pkt_stride, igdsp_frame_stats *d_stats,
+                                     igdsp_rtp_info *d_info, igdsp_aggregate *d_agg, uint32_t rank, void *stream)
+{
+    if (!ctx) return IGDSP_EINVAL;
+    if ((uint64_t)C * F == 0) return IGDSP_OK;
+    if (!d_packets || !d_codec || !d_radio || !d_stats || rank >= IGDSP_AGG_MAX_RANKS) return IGDSP_EINVAL;
+    if (int rc = check_shape(C, F, IGDSP_SAMPLES_PER_FRAME)) return rc;
+    if (pkt_stride < 180u || (pkt_stride & 3u) || pkt_stride > 2048u || (uint64_t)C * F * pkt_stride > 0xFFFFFFFFull * 4ull)
+        return IGDSP_EINVAL;
+    if (((uint64_t)C * F) % 64u || (reinterpret_cast<uintptr_t>(d_packets) & 3u) || (reinterpret_cast<uintptr_t>(d_stats) & 15u) ||
+        (reinterpret_cast<uintptr_t>(d_info) & 7u) || (reinterpret_cast<uintptr_t>(d_sizes) & 1u))
+        return fail(ctx, IGDSP_EINVAL, "decode_meter_packets_mixed needs C*F % 64 == 0, dword-aligned packets, 16-byte aligned stats");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_decode_meter_rtp(cfg_of(ctx), d_packets, d_sizes, d_codec, C, F, pkt_stride, 12, d_stats, d_info, d_agg, rank, pick(ctx, stream), d_radio));
+    return IGDSP_OK;
+}
+
+
 int igdsp_g726_reorder(igdsp_ctx *ctx, const uint8_t *d_in, uint8_t *d_out, uint64_t n_bytes, int mode, void *stream)
 {
     if (!ctx || mode < 1 || mode > 4) return IGDSP_EINVAL;

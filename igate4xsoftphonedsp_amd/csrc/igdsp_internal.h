@@ -31,7 +31,7 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant,
                                igdsp_aggregate *agg, uint32_t rank, hipStream_t s);
 hipError_t launch_decode_meter_rtp(const LaunchCfg &cfg, const uint8_t *slots, const uint16_t *sizes, const uint8_t *codec, uint32_t C,
                                    uint32_t F, uint32_t stride, uint32_t hdr, igdsp_frame_stats *stats, igdsp_rtp_info *info,
-                                   igdsp_aggregate *agg, uint32_t rank, hipStream_t s);
+                                   igdsp_aggregate *agg, uint32_t rank, hipStream_t s, const uint8_t *radio = nullptr);
 hipError_t launch_diag_chunk32(const LaunchCfg &cfg, const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F,
                                igdsp_frame_stats *stats, uint64_t *diag, hipStream_t s);
 hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t *codec,

@@ -864,12 +864,17 @@ __device__ __forceinline__ void bq_finish(uint32_t *gq, uint32_t G)             
     if (threadIdx.x == 0 && atomicAdd(gq + 1, 1u) == G - 1u) { gq[0] = 0u; gq[1] = 0u; }
 }
 
-template <bool AGG, bool SLOT>
+// MIXED (packed form only): the header length is per channel, 20 bytes where radio[c] != 0 and 12 elsewhere (SIP and
+// ED-137 legs in one launch, as in the reference's process); `hdr` is then ignored.  The radio flags travel like the
+// codec ids: the frame lanes fetch them one item ahead and a ballot hands every piece its packet's bit.
+template <bool AGG, bool SLOT, bool MIXED = false>
 __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     const uint8_t *__restrict__ slots, const uint16_t *__restrict__ sizes, const uint8_t *__restrict__ codec, uint32_t C,
     uint32_t n_frames, uint32_t stride, uint32_t hdr, igdsp_frame_stats *__restrict__ stats, igdsp_rtp_info *__restrict__ info,
-    igdsp_aggregate *agg, uint32_t rank, uint32_t *gqueue)
+    igdsp_aggregate *agg, uint32_t rank, uint32_t *gqueue, const uint8_t *__restrict__ radio = nullptr)
 {
+    static_assert(!(SLOT && MIXED), "slots always hold 20-byte headers");
+    if (MIXED) hdr = 12u;
     __shared__ uint2 lds[kLutEntries + kRtpWaves * kRtpStrip];
     __shared__ BlockQueue<kRtpWaves> bq;
     uint32_t gb1 = 0;
@@ -902,11 +907,19 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     const uint32_t G = gridDim.x;
     const uint32_t n_super = n_frames / kSuperFrames;
     const uint64_t super_bytes = (uint64_t)kSuperFrames * (SLOT ? (uint32_t)IGDSP_SLOT_BYTES : stride);
-    const uint32_t full = SLOT ? 180u : hdr + (uint32_t)kFrame;
-    const uint32_t hbytes = SLOT ? 20u : hdr;
     uint64_t a_sumsq = 0;
     uint32_t a_frames = 0, a_sil = 0, a_clip = 0, a_bm = 0, a_peak = 0;
 
+    auto fetch_radio = [&](uint32_t sidx) { return MIXED ? (uint32_t)radio[(sidx * (uint32_t)kSuperFrames + lane) % C] : 0u; };
+    // byte offsets of this lane's pieces for an item whose packets' radio bits are rm: payload pieces of radio packets sit 8 bytes further
+    auto offsets = [&](uint64_t rm, uint32_t (&o0)[kRtpHalfLoads], uint32_t (&o1)[kRtpHalfLoads]) {
+#pragma unroll
+        for (int j = 0; j < kRtpHalfLoads; ++j) {
+            const uint32_t b0 = (uint32_t)(rm >> fr[j]) & 1u, b1 = (uint32_t)(rm >> (fr[j] + 32u)) & 1u;
+            o0[j] = roff0[j] + (hs[j] == 0u ? 8u * b0 : 0u);
+            o1[j] = roff1[j] + (hs[j] == 0u ? 8u * b1 : 0u);
+        }
+    };
     auto ld = [&](const uint8_t *b, uint32_t o) { return SLOT ? ld_stream(reinterpret_cast<const uint4 *>(b + o)) : ld16_dw(b + o); };
     auto fetch_pt = [&](uint32_t sidx) { return (uint32_t)codec[(sidx * (uint32_t)kSuperFrames + lane) % C]; };
     const uint32_t n_batches = (n_super + (uint32_t)kRtpWaves - 1u) / (uint32_t)kRtpWaves;
@@ -916,12 +929,22 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     if (sidx < n_super) {
         uint4 X[kRtpHalfLoads], Y[kRtpHalfLoads];
         uint32_t cur_pt = fetch_pt(sidx);
+        uint32_t cur_radio = fetch_radio(sidx);
         {
             const uint8_t *b0 = slots + (uint64_t)sidx * super_bytes;
+            if (MIXED) {
+                uint32_t o0[kRtpHalfLoads], o1[kRtpHalfLoads];
+                offsets(__ballot(cur_radio != 0u), o0, o1);
 #pragma unroll
-            for (int j = 0; j < kRtpHalfLoads; ++j) X[j] = ld(b0, roff0[j]);
+                for (int j = 0; j < kRtpHalfLoads; ++j) X[j] = ld(b0, o0[j]);
 #pragma unroll
-            for (int j = 0; j < kRtpHalfLoads; ++j) Y[j] = ld(b0, roff1[j]);
+                for (int j = 0; j < kRtpHalfLoads; ++j) Y[j] = ld(b0, o1[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kRtpHalfLoads; ++j) X[j] = ld(b0, roff0[j]);
+#pragma unroll
+                for (int j = 0; j < kRtpHalfLoads; ++j) Y[j] = ld(b0, roff1[j]);
+            }
         }
         uint32_t s_next = grab();
         for (;;) {
@@ -939,10 +962,20 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
             }
             const uint8_t *nbase = slots + (uint64_t)s_load * super_bytes;
             const uint32_t nxt_pt = fetch_pt(s_load);
+            const uint32_t nxt_radio = fetch_radio(s_load);
+            const uint32_t hbytes = SLOT ? 20u : (MIXED ? (cur_radio != 0u ? 20u : 12u) : hdr);   // of this lane's own packet
+            const uint32_t full = hbytes + (uint32_t)kFrame;
             uint32_t my_size = full;
             if (!SLOT && sizes != nullptr) my_size = sizes[f0 + lane];
-            rtp_half<SLOT>(lds, strip, X, lm0, pm, hs, off, lane, nbase, roff0);
-            rtp_half<SLOT>(lds, strip + kRtpStrip / 2, Y, lm1, pm, hs, off, lane, nbase, roff1);
+            if (MIXED) {
+                uint32_t n0[kRtpHalfLoads], n1[kRtpHalfLoads];
+                offsets(__ballot(nxt_radio != 0u), n0, n1);
+                rtp_half<SLOT>(lds, strip, X, lm0, pm, hs, off, lane, nbase, n0);
+                rtp_half<SLOT>(lds, strip + kRtpStrip / 2, Y, lm1, pm, hs, off, lane, nbase, n1);
+            } else {
+                rtp_half<SLOT>(lds, strip, X, lm0, pm, hs, off, lane, nbase, roff0);
+                rtp_half<SLOT>(lds, strip + kRtpStrip / 2, Y, lm1, pm, hs, off, lane, nbase, roff1);
+            }
             const uint32_t s_after = has_next ? grab() : 0xFFFFFFFFu;   // its LDS round trip hides under the fold below
             wave_lds_fence();
             {
@@ -996,6 +1029,7 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
             sidx = s_next;
             s_next = s_after;
             cur_pt = nxt_pt;
+            cur_radio = nxt_radio;
         }
     }
     bq_finish(gqueue, G);
@@ -2004,19 +2038,23 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
 
 hipError_t launch_decode_meter_rtp(const LaunchCfg &cfg, const uint8_t *slots, const uint16_t *sizes, const uint8_t *codec, uint32_t C,
                                    uint32_t F, uint32_t stride, uint32_t hdr, igdsp_frame_stats *stats, igdsp_rtp_info *info,
-                                   igdsp_aggregate *agg, uint32_t rank, hipStream_t s)
+                                   igdsp_aggregate *agg, uint32_t rank, hipStream_t s, const uint8_t *radio)
 {
-    // stride == 0: the 192-byte slot format; otherwise packets packed at `stride` with a `hdr`-byte RTP header
+    // stride == 0: the 192-byte slot format; otherwise packets packed at `stride` with a `hdr`-byte RTP header, or, with
+    // `radio`, a per-channel 20 / 12-byte header
     const uint32_t n_frames = C * F;                       // caller guarantees a multiple of 64
     if (n_frames == 0) return hipSuccess;
     const uint32_t grid = blocks_for(n_frames / kSuperFrames, kRtpWaves, (uint32_t)cfg.compute_units);
     const dim3 blk(kRtpWaves * 64);
     if (stride == 0) {
-        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, cfg.gqueue);
-        else     hipLaunchKernelGGL((k_meter_rtp64<false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, cfg.gqueue);
+        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, cfg.gqueue, radio);
+        else     hipLaunchKernelGGL((k_meter_rtp64<false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, cfg.gqueue, radio);
+    } else if (radio != nullptr) {
+        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, cfg.gqueue, radio);
+        else     hipLaunchKernelGGL((k_meter_rtp64<false, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, cfg.gqueue, radio);
     } else {
-        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, cfg.gqueue);
-        else     hipLaunchKernelGGL((k_meter_rtp64<false, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, cfg.gqueue);
+        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, cfg.gqueue, radio);
+        else     hipLaunchKernelGGL((k_meter_rtp64<false, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, cfg.gqueue, radio);
     }
     return hipGetLastError();
 }

@@ -295,6 +295,14 @@ int igdsp_decode_meter_packets(igdsp_ctx *ctx, const uint8_t *d_packets, const u
                                igdsp_frame_stats *d_stats, igdsp_rtp_info *d_info,
                                igdsp_aggregate *d_agg, uint32_t rank, void *stream);
 
+/* The same again with a PER-CHANNEL header length: d_radio[c] != 0 -> 20-byte ED-137 header, 0 -> 12-byte RTP header
+ * (radio legs and plain SIP legs in one launch, as in the reference's process, TransportAdapter.cpp:265-292).
+ * pkt_stride >= 180.  Metered iff size == header + 160 and PT == codec[c]; info as igdsp_depayload would give it. */
+int igdsp_decode_meter_packets_mixed(igdsp_ctx *ctx, const uint8_t *d_packets, const uint16_t *d_sizes, const uint8_t *d_codec,
+                                     const uint8_t *d_radio, uint32_t n_channels, uint32_t n_frames, uint32_t pkt_stride,
+                                     igdsp_frame_stats *d_stats, igdsp_rtp_info *d_info,
+                                     igdsp_aggregate *d_agg, uint32_t rank, void *stream);
+
 /* ---- G.726 code-word reorder (RoIP_ED137::changeUplinkOrder, roip_ed137.cpp:6379-6499) ----
  * Repacks G.726 code words between the RFC 3551 and AAL2 bit orders, bug-for-bug as the reference
  * does it on its (unsigned-char) target:

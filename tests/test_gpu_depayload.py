@@ -276,3 +276,60 @@ def test_fused_packed_packets_meter(ctx, orc, hdr, stride, C_, F_, with_sizes):
     assert L.igdsp_decode_meter_packets(ctx.h, p, None, p, 64, 1, 178, 20, p, None, None, 0, None) == -22   # stride < hdr+160
     assert L.igdsp_decode_meter_packets(ctx.h, p, None, p, 64, 1, 182, 20, p, None, None, 0, None) == -22   # stride % 4
     assert L.igdsp_decode_meter_packets(ctx.h, p, None, p, 33, 1, 180, 20, p, None, None, 0, None) == -22   # C*F % 64
+
+
+@pytest.mark.parametrize("stride,C_,F_", [(180, 64, 3), (184, 96, 2), (256, 128, 2)])
+def test_fused_packed_packets_mixed_headers(ctx, orc, stride, C_, F_):
+    """igdsp_decode_meter_packets_mixed: radio (20-byte header) and SIP (12-byte header) channels in ONE launch; same
+    oracle relations as the single-header form, per channel."""
+    torch = gu.torch_cuda()
+    n = 160
+    rng = np.random.default_rng(stride + C_)
+    radio = (rng.integers(0, 2, C_)).astype(np.uint8)
+    radio[:4] = [1, 0, 0, 1]
+    codec = np.where(np.arange(C_) % 3 == 0, 8, 0).astype(np.uint8)
+    pk = orc.gen_uniform(F_ * C_ * stride, seed=stride).reshape(F_, C_, stride).copy()
+    sizes = np.zeros((F_, C_), np.uint16)
+    for f in range(F_):
+        for c in range(C_):
+            hdr = 20 if radio[c] else 12
+            kind = int(rng.integers(0, 10))
+            pt = int(codec[c]) if kind < 6 else [123, 18, 8 - int(codec[c]), 96][kind - 6]
+            plen = n if kind != 9 else 24
+            if kind == 6:
+                plen = 0
+            body = orc.gen_uniform(max(plen, 1), seed=f * 1000 + c).tobytes()[:plen]
+            pkt = bytearray(hu.rtp_packet(pt, f, body, bool(radio[c]), int(rng.integers(0, 2 ** 32))))
+            if rng.integers(0, 6) == 0:
+                pkt[1] |= 0x80
+            pk[f, c, :len(pkt)] = np.frombuffer(bytes(pkt), np.uint8)
+            sizes[f, c] = len(pkt) if kind != 8 or f % 2 else int(rng.integers(0, hdr))
+    d_st, d_info, d_agg = gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.dev_zeros(F_ * C_ * 8, 0xEE), gu.dev_zeros(capi.AGGREGATE.itemsize)
+    ctx.decode_meter_packets_mixed(gu.to_dev(pk), gu.to_dev(sizes), gu.to_dev(codec), gu.to_dev(radio), C_, F_, stride, d_st, info=d_info, agg=d_agg, rank=3)
+    torch.cuda.synchronize()
+    epl, elen, einfo = orc.depayload(pk, sizes, radio, n)
+    ginfo = gu.to_host(d_info, capi.RTP_INFO, (F_, C_))
+    for fld in capi.RTP_INFO.names:
+        assert np.array_equal(ginfo[fld], einfo[fld]), fld
+    hdrs = np.where(radio, 20, 12)[None, :]
+    metered = (sizes == hdrs + n) & (einfo["pt"] == codec[None, :]) & np.isin(einfo["pt"], (0, 8))
+    assert metered[:, radio == 1].any() and metered[:, radio == 0].any() and (~metered).any()
+    est = orc.decode_meter(epl, codec)
+    gst = gu.to_host(d_st, capi.FRAME_STATS, (F_, C_))
+    gu.assert_stats_equal(gst[metered].reshape(1, -1), est[metered].reshape(1, -1), n=n)
+    emp = gst[~metered]
+    assert np.all(emp["flags"] == capi.FLAG_EMPTY) and np.all(emp["sumsq"] == 0) and np.all(emp["peak"] == 0)
+    agg = gu.to_host(d_agg, capi.AGGREGATE)[0]
+    assert int(agg["frames"]) == int(metered.sum())
+    assert int(agg["sumsq"]) == int(est["sumsq"][metered].sum(dtype=np.uint64))
+    assert int(agg["peak_slot"][3]) == int(est["peak"][metered].max())
+    # all-radio through the mixed entry == the single-header entry, record for record
+    ones = np.ones((C_,), np.uint8)
+    d_a, d_b = gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.dev_zeros(F_ * C_ * 16, 0xEE)
+    ctx.decode_meter_packets_mixed(gu.to_dev(pk), gu.to_dev(sizes), gu.to_dev(codec), gu.to_dev(ones), C_, F_, stride, d_a)
+    ctx.decode_meter_packets(gu.to_dev(pk), gu.to_dev(sizes), gu.to_dev(codec), C_, F_, stride, 20, d_b)
+    torch.cuda.synchronize()
+    assert gu.to_host(d_a, np.uint8).tobytes() == gu.to_host(d_b, np.uint8).tobytes()
+    p_ = d_st.data_ptr()
+    assert ctx.L.igdsp_decode_meter_packets_mixed(ctx.h, p_, None, p_, None, 64, 1, 180, p_, None, None, 0, None) == -22   # radio missing
+    assert ctx.L.igdsp_decode_meter_packets_mixed(ctx.h, p_, None, p_, p_, 64, 1, 176, p_, None, None, 0, None) == -22    # stride < 180
