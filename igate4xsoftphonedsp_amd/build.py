@@ -19,9 +19,9 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libigdsp.so")
 HOST_LIB = os.path.join(PKG, "libigdsp_host.so")
 
-DEVICE_SOURCES = ["igdsp_kernels.hip", "igdsp_capi.hip"]
+DEVICE_SOURCES = ["igdsp_kernels.hip", "igdsp_capi.hip", "igdsp_io.hip"]
 HOST_SOURCES = ["igdsp_host.cpp"]          # C++ mirror of the reference's adapter/hook interface
-HEADERS = ["igdsp_internal.h", os.path.join(INCLUDE, "igdsp.h")]
+HEADERS = ["igdsp_internal.h", "igdsp_ctx.h", os.path.join(INCLUDE, "igdsp.h")]
 
 
 def _hipcc() -> str:

@@ -55,6 +55,23 @@ class Level(C.Structure):
                 ("percent", C.c_int32), ("peak_hold", C.c_uint16), ("reserved", C.c_uint16), ("frames", C.c_uint32)]
 
 
+IO_INPUT, IO_RECORD, IO_BULK = 0, 1, 2
+
+
+class IoBuf(C.Structure):
+    _fields_ = [("bytes", C.c_size_t), ("role", C.c_uint32), ("reserved", C.c_uint32), ("ptr", C.c_void_p)]
+
+
+class IoReport(C.Structure):
+    _fields_ = [("placed", C.c_uint32), ("bulk_spread", C.c_uint32), ("classes_found", C.c_uint32), ("chunks_explored", C.c_uint32),
+                ("probes", C.c_uint32), ("reseeds", C.c_uint32), ("chunk_bytes", C.c_uint64), ("explored_bytes", C.c_uint64),
+                ("probe_ms_same", C.c_float), ("probe_ms_other", C.c_float), ("setup_ms", C.c_float), ("reserved2", C.c_float)]
+
+    def as_dict(self):
+        return {k: (round(getattr(self, k), 4) if isinstance(getattr(self, k), float) else getattr(self, k))
+                for k, _ in self._fields_ if not k.startswith("reserved")}
+
+
 class IgdspError(RuntimeError):
     def __init__(self, code: int, where: str, detail: str = ""):
         self.code = code
@@ -92,6 +109,8 @@ PROTOTYPES = [
     ("igdsp_dev_alloc", _int, [_vp, C.POINTER(_vp), C.c_size_t]),
     ("igdsp_dev_free", _int, [_vp, _vp]),
     ("igdsp_dev_alloc_far", _int, [_vp, C.POINTER(_vp), C.c_size_t, _vp, C.c_size_t, _u32, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("igdsp_io_alloc", _int, [_vp, C.POINTER(IoBuf), _u32, C.c_size_t, C.POINTER(_vp), C.POINTER(IoReport)]),
+    ("igdsp_io_free", _int, [_vp, _vp]),
     ("igdsp_copy_h2d", _int, [_vp, _vp, _vp, C.c_size_t]),
     ("igdsp_copy_d2h", _int, [_vp, _vp, _vp, C.c_size_t]),
     ("igdsp_dev_memset", _int, [_vp, _vp, _int, C.c_size_t]),
@@ -268,6 +287,27 @@ class Context:
     def stream_read(self, src, n_bytes, sink, stream=None):
         self._ck(self.L.igdsp_stream_read(self.h, _ptr(src), n_bytes, _ptr(sink), stream), "igdsp_stream_read")
 
+    # -- device memory
+    def dev_alloc(self, nbytes: int) -> int:
+        p = _vp()
+        self._ck(self.L.igdsp_dev_alloc(self.h, C.byref(p), nbytes), "igdsp_dev_alloc")
+        return p.value
+
+    def dev_free(self, ptr: int):
+        self._ck(self.L.igdsp_dev_free(self.h, ptr), "igdsp_dev_free")
+
+    def dev_memset(self, ptr, value: int, nbytes: int):
+        self._ck(self.L.igdsp_dev_memset(self.h, _ptr(ptr), value, nbytes), "igdsp_dev_memset")
+
+    def io_alloc(self, bufs, explore_limit_bytes: int = 0):
+        """bufs = [(nbytes, role), ...] -> (IoSet, [device pointers], report dict): igdsp_io_alloc."""
+        arr = (IoBuf * len(bufs))()
+        for a, (nb, role) in zip(arr, bufs):
+            a.bytes, a.role = int(nb), int(role)
+        st, rep = _vp(), IoReport()
+        self._ck(self.L.igdsp_io_alloc(self.h, arr, len(bufs), explore_limit_bytes, C.byref(st), C.byref(rep)), "igdsp_io_alloc")
+        return IoSet(self, st), [a.ptr for a in arr], rep.as_dict()
+
     def sync(self, stream=None):
         self._ck(self.L.igdsp_sync(self.h, stream), "igdsp_sync")
 
@@ -279,6 +319,35 @@ class Context:
 
     def timer(self):
         return Timer(self)
+
+
+class IoSet:
+    """Owner of one igdsp_io_alloc buffer set (freed by close() / igdsp_io_free)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx, self.h = ctx, handle
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.L.igdsp_io_free(self.ctx.h, self.h)
+        self.h = None
+
+
+class DevView:
+    """A raw device range as something torch can wrap without copying: torch.as_tensor(DevView(ptr, n), device="cuda")
+    gives a uint8 tensor over it (plumbing for tests / bench; the memory stays owned by whoever allocated it)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 3, "strides": None}
+
+
+def as_tensor(ptr: int, nbytes: int, dtype=None, shape=None):
+    import torch
+
+    t = torch.as_tensor(DevView(ptr, nbytes), device="cuda")
+    if dtype is not None:
+        t = t.view(dtype)
+    return t.view(shape) if shape is not None else t
 
 
 class Timer:

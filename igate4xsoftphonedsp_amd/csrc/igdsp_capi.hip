@@ -4,7 +4,7 @@
 // (roip_ed137.cpp:6500-6587), call-id routing (roip_ed137.cpp:6519-6534) and
 // argument validation.  There is NO CPU compute path here: when the HIP runtime
 // or a gfx950 device is missing every entry fails with IGDSP_ENODEV.
-#include "igdsp_internal.h"
+#include "igdsp_ctx.h"
 
 #include <algorithm>
 #include <atomic>
@@ -19,85 +19,6 @@
 #include <vector>
 
 using namespace igdsp;
-
-namespace {
-constexpr uint32_t kSlot = IGDSP_MAX_PAYLOAD;          // staging slot bytes per channel (tp_adapter::payload_buff[256])
-constexpr uint32_t kNoChan = 0xFFFFFFFFu;
-constexpr int32_t kDirectCalls = 1 << 16;              // pjsua_call_id values are small non-negative ints
-}  // namespace
-
-struct igdsp_ctx {
-    int device = -1;
-    int cus = 0;
-    std::string name;
-    uint32_t max_channels = 0;
-    hipStream_t stream = nullptr;
-    int variant = 0;
-    std::string err;
-
-    // a4 routing: direct table for 0 <= call_id < 65536 (lock-free reads), map beyond
-    std::vector<std::atomic<uint32_t>> direct;
-    std::unordered_map<int32_t, uint32_t> far;
-    std::mutex far_mu;
-
-    // staging (host pinned): slab[c][256], len[c] (0 = nothing staged), pt[c]
-    uint8_t *h_slab = nullptr;
-    uint16_t *h_len = nullptr;
-    uint8_t *h_pt = nullptr;
-    std::vector<std::atomic_flag> slot_lock;
-    std::atomic<uint32_t> hi_water{0};                 // 1 + highest channel ever staged
-
-    // upload mirrors + results
-    uint8_t *h_up = nullptr;        // pinned compacted copy taken under the slot locks
-    uint16_t *h_up_len = nullptr;
-    uint8_t *h_up_pt = nullptr;
-    uint8_t *d_slab = nullptr;
-    uint16_t *d_len = nullptr;
-    uint8_t *d_pt = nullptr;
-    igdsp_frame_stats *d_stats = nullptr;
-    igdsp_frame_stats *h_stats = nullptr;               // pinned: last metered record per channel
-    igdsp_frame_stats *h_fresh = nullptr;               // pinned: this flush's records (EMPTY where nothing was staged)
-    igdsp_chan_hold *d_hold = nullptr;
-    igdsp_chan_hold *h_hold = nullptr;                  // pinned
-    std::vector<uint32_t> frames_seen;
-    std::mutex flush_mu;
-
-    // device-wide work counters: a ring so that launches in flight on different streams never share one
-    uint32_t *d_queues = nullptr;                       // kQueueRing x 32 words (128 B apart)
-    std::atomic<uint32_t> queue_turn{0};
-    bool global_queue = true;                           // device-wide batched work queue for k_meter_chunk64 (IGDSP_GLOBAL_QUEUE=0:
-                                                        // static per-block batches).  Removes the inter-CU tail: -2.5 % on the
-                                                        // headline launch once the outputs sit in another memory region than the
-                                                        // payload (tools/kernel_ab.py); neutral when they share a region.
-};
-namespace { constexpr uint32_t kQueueRing = 64; }
-
-static int fail(igdsp_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
-{
-    if (ctx) {
-        char buf[256];
-        if (e != hipSuccess) std::snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
-        else std::snprintf(buf, sizeof buf, "%s", what);
-        ctx->err = buf;
-    }
-    return code;
-}
-
-#define HIP_TRY(ctx, call)                                                    \
-    do {                                                                      \
-        hipError_t e_ = (call);                                               \
-        if (e_ != hipSuccess) return fail((ctx), IGDSP_EDEVICE, #call, e_);   \
-    } while (0)
-
-// NULL means what it means everywhere in HIP: the legacy default (null) stream, so a caller that
-// passes nothing stays ordered with its own default-stream work (e.g. torch tensors it just filled).
-static inline hipStream_t pick(igdsp_ctx *, void *stream) { return (hipStream_t)stream; }
-static inline LaunchCfg cfg_of(igdsp_ctx *ctx)
-{
-    uint32_t *q = nullptr;
-    if (ctx->global_queue && ctx->d_queues) q = ctx->d_queues + 32u * (ctx->queue_turn.fetch_add(1, std::memory_order_relaxed) % kQueueRing);
-    return LaunchCfg{ctx->cus, q};
-}
 
 extern "C" {
 
@@ -188,7 +109,7 @@ int igdsp_device_info(const igdsp_ctx *ctx, int *device, int *compute_units, cha
 
 int igdsp_set_variant(igdsp_ctx *ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant > 3) return IGDSP_EINVAL;
+    if (!ctx || variant < 0 || variant > 4) return IGDSP_EINVAL;
     ctx->variant = variant;
     return IGDSP_OK;
 }
@@ -367,14 +288,11 @@ int igdsp_roundtrip_peakhold(igdsp_ctx *ctx, const uint8_t *d_payload, const uin
     if (!d_payload || !d_codec || !d_out || !d_stats || !d_hold) return IGDSP_EINVAL;
     if (variant != IGDSP_ENC_SUN16 && variant != IGDSP_ENC_G191) return IGDSP_EINVAL;
     if (int rc = check_shape(C, F, n)) return rc;
-    // the fused channel-major kernel covers the tuned geometry; anything else is rejected
-    // rather than silently routed elsewhere (callers compose decode_meter + encode + hold_update).
-    const bool fused_ok = (n == (uint32_t)kFrame) && (C % 64u == 0) &&
-                          ((reinterpret_cast<uintptr_t>(d_payload) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) &&
-                          ((reinterpret_cast<uintptr_t>(d_stats) & 15u) == 0);
-    if (!fused_ok) return fail(ctx, IGDSP_EINVAL, "roundtrip_peakhold needs n == 160, C % 64 == 0 and 16-byte aligned buffers");
+    if ((reinterpret_cast<uintptr_t>(d_stats) & 7u) || (reinterpret_cast<uintptr_t>(d_hold) & 7u)) return IGDSP_EINVAL;   // natural struct alignment
+    // every shape is served: whole groups of 64 channels of 160-byte frames by the fused channel-group-major kernel,
+    // the remaining channels and every other geometry by the general wave-per-channel kernel (launch_roundtrip)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_roundtrip(cfg_of(ctx), d_payload, d_codec, C, F, n, d_out, d_stats, d_hold, d_gate, variant, pick(ctx, stream)));
+    HIP_TRY(ctx, launch_roundtrip(cfg_of(ctx), ctx->variant, d_payload, d_codec, C, F, n, d_out, d_stats, d_hold, d_gate, variant, pick(ctx, stream)));
     return IGDSP_OK;
 }
 
@@ -384,6 +302,7 @@ int igdsp_hold_update(igdsp_ctx *ctx, const igdsp_frame_stats *d_stats, uint32_t
     if (!ctx) return IGDSP_EINVAL;
     if ((uint64_t)C * F == 0) return IGDSP_OK;
     if (!d_stats || !d_hold) return IGDSP_EINVAL;
+    if (int rc = check_shape(C, F, n)) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_hold_update(d_stats, nullptr, C, F, n, d_hold, d_gate, pick(ctx, stream)));
     return IGDSP_OK;

@@ -1,0 +1,91 @@
+// Private to the C-ABI translation units (igdsp_capi.hip, igdsp_io.hip): the context object and the small helpers every
+// entry uses.  Not part of the ABI (include/igdsp.h is).
+#pragma once
+#include "igdsp_internal.h"
+
+#include <atomic>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+constexpr uint32_t kSlot = IGDSP_MAX_PAYLOAD;          // staging slot bytes per channel (tp_adapter::payload_buff[256])
+constexpr uint32_t kNoChan = 0xFFFFFFFFu;
+constexpr int32_t kDirectCalls = 1 << 16;              // pjsua_call_id values are small non-negative ints
+}  // namespace
+
+struct igdsp_ctx {
+    int device = -1;
+    int cus = 0;
+    std::string name;
+    uint32_t max_channels = 0;
+    hipStream_t stream = nullptr;
+    int variant = 0;
+    std::string err;
+
+    // a4 routing: direct table for 0 <= call_id < 65536 (lock-free reads), map beyond
+    std::vector<std::atomic<uint32_t>> direct;
+    std::unordered_map<int32_t, uint32_t> far;
+    std::mutex far_mu;
+
+    // staging (host pinned): slab[c][256], len[c] (0 = nothing staged), pt[c]
+    uint8_t *h_slab = nullptr;
+    uint16_t *h_len = nullptr;
+    uint8_t *h_pt = nullptr;
+    std::vector<std::atomic_flag> slot_lock;
+    std::atomic<uint32_t> hi_water{0};                 // 1 + highest channel ever staged
+
+    // upload mirrors + results
+    uint8_t *h_up = nullptr;        // pinned compacted copy taken under the slot locks
+    uint16_t *h_up_len = nullptr;
+    uint8_t *h_up_pt = nullptr;
+    uint8_t *d_slab = nullptr;
+    uint16_t *d_len = nullptr;
+    uint8_t *d_pt = nullptr;
+    igdsp_frame_stats *d_stats = nullptr;
+    igdsp_frame_stats *h_stats = nullptr;               // pinned: last metered record per channel
+    igdsp_frame_stats *h_fresh = nullptr;               // pinned: this flush's records (EMPTY where nothing was staged)
+    igdsp_chan_hold *d_hold = nullptr;
+    igdsp_chan_hold *h_hold = nullptr;                  // pinned
+    std::vector<uint32_t> frames_seen;
+    std::mutex flush_mu;
+
+    // device-wide work counters: a ring so that launches in flight on different streams never share one
+    uint32_t *d_queues = nullptr;                       // kQueueRing x 32 words (128 B apart)
+    std::atomic<uint32_t> queue_turn{0};
+    bool global_queue = true;                           // device-wide batched work queue for k_meter_chunk64 (IGDSP_GLOBAL_QUEUE=0:
+                                                        // static per-block batches).  Removes the inter-CU tail: -2.5 % on the
+                                                        // headline launch once the outputs sit in another memory region than the
+                                                        // payload (tools/kernel_ab.py); neutral when they share a region.
+};
+namespace { constexpr uint32_t kQueueRing = 64; }
+
+static inline int fail(igdsp_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        char buf[256];
+        if (e != hipSuccess) std::snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        else std::snprintf(buf, sizeof buf, "%s", what);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                    \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) return fail((ctx), IGDSP_EDEVICE, #call, e_);   \
+    } while (0)
+
+// NULL means what it means everywhere in HIP: the legacy default (null) stream, so a caller that
+// passes nothing stays ordered with its own default-stream work (e.g. torch tensors it just filled).
+static inline hipStream_t pick(igdsp_ctx *, void *stream) { return (hipStream_t)stream; }
+static inline igdsp::LaunchCfg cfg_of(igdsp_ctx *ctx)
+{
+    uint32_t *q = nullptr;
+    if (ctx->global_queue && ctx->d_queues) q = ctx->d_queues + 32u * (ctx->queue_turn.fetch_add(1, std::memory_order_relaxed) % kQueueRing);
+    return igdsp::LaunchCfg{ctx->cus, q};
+}
+

@@ -7,8 +7,8 @@
 
 namespace igdsp {
 
-// Geometry of the tuned n == 160 path ("chunk32"): one wavefront owns 32
-// consecutive channel-frames = 5120 contiguous bytes = 5 wave-wide 16 B/lane loads.
+// Geometry of the tuned n == 160 path: a wavefront owns a super-chunk of 64 consecutive channel-frames
+// (10 240 contiguous bytes), processed as two halves of 32 frames = 5120 bytes = 5 wave-wide 16 B/lane loads each.
 constexpr int kFrame = IGDSP_SAMPLES_PER_FRAME;        // 160 B
 constexpr int kChunkFrames = 32;
 constexpr int kChunkBytes = kChunkFrames * kFrame;     // 5120
@@ -38,7 +38,7 @@ hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t
                          uint32_t C, uint32_t F, uint32_t n, uint8_t *out, int variant, hipStream_t s);
 hipError_t launch_encode_table(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t *codec, uint32_t C, uint32_t F, uint32_t n,
                                uint8_t *out, int variant, hipStream_t s);
-hipError_t launch_roundtrip(const LaunchCfg &cfg, const uint8_t *payload, const uint8_t *codec,
+hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint8_t *payload, const uint8_t *codec,
                             uint32_t C, uint32_t F, uint32_t n, uint8_t *out, igdsp_frame_stats *stats,
                             igdsp_chan_hold *hold, const uint8_t *gate, int variant, hipStream_t s);
 hipError_t launch_hold_update(const igdsp_frame_stats *stats, const uint16_t *len, uint32_t C, uint32_t F, uint32_t n,

@@ -1,0 +1,561 @@
+// igdsp_io.hip — placement-aware allocation of the hot path's input / output buffers (igdsp_io_alloc, include/igdsp.h).
+//
+// Why it exists.  On MI355X a kernel that READS one class of device memory and WRITES another runs ~13 % faster than one
+// that reads and writes the same class, and a bulk write stream spread over two classes (neither the inputs') is another
+// 5-8 % faster (three classes of ~96 GB, in runs of tens of GiB of consecutive allocations — consistent with
+// the three stack-ID ranks of the 12-high HBM3E stacks: write-to-read turnaround is paid inside a rank).  Which class an
+// allocation lands in is not visible through any API and differs per process, so the only way to place buffers is to
+// measure.  Round 1 did that in bench.py (a 200 GB arena and timed launches); a host that followed INTEGRATION.md got the
+// slow case.  This file moves it into the product:
+//
+//   * physical memory is taken in CHUNKS (hipMemCreate, 128 MiB) and each chunk is classified by timing the bare
+//     read + record-store stream (the meter kernel's traffic, k_stream_rw) reading the caller's INPUT buffers and writing
+//     the chunk;
+//   * buffers are virtual address ranges (hipMemAddressReserve) onto which chunks of the wanted class are mapped:
+//     INPUT buffers first (their class is "A" by definition), RECORD buffers from chunks of another class, BULK buffers
+//     with their first half from one non-A class and their second half from the other (the queue-driven kernels visit the
+//     two halves of a bulk output alternately, spread_batch in igdsp_kernels.hip);
+//   * exploration is sparse (every 16th chunk is probed until a new class shows up, then its neighbours) and bounded by
+//     `explore_limit_bytes`; everything not mapped is released before returning.
+//
+// When the virtual-memory API is unavailable, the inputs are too small for the probe to mean anything (< 512 MiB: the
+// batch lives in the 256 MiB Infinity Cache anyway) or no second class is found inside the limit, the buffers are still
+// returned — consecutive chunks / plain hipMalloc — and the report says so (placed = 0).  No CPU path is involved anywhere.
+#include "igdsp_ctx.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+using namespace igdsp;
+
+struct igdsp_io_set {
+    struct Map { void *va = nullptr; size_t bytes = 0; std::vector<hipMemGenericAllocationHandle_t> handles; };
+    std::vector<Map> maps;            // VMM path: one reserved range per buffer, chunk handles mapped back to back
+    std::vector<void *> plain;        // fallback path: hipMalloc'ed buffers
+    size_t chunk = 0;
+    int device = 0;
+};
+
+namespace {
+
+constexpr size_t kSrcChunks = 10;     // chunks behind a probe source: 1.25 GiB streamed per probe launch, far more than the 256 MiB Infinity Cache
+
+struct Chunk {
+    hipMemGenericAllocationHandle_t h{};
+    float tA = -1.f;                  // probe time as the WRITE side against source A (< 0: not timed)
+    float tB = -1.f;                  // ... against source B
+    bool used = false;                // handed to a buffer (not to be released)
+    bool mapped = false;              // currently mapped on its scratch slot
+    bool in_src = false;              // currently part of a probe source
+};
+
+// A probe source: kSrcChunks chunks mapped back to back on an address range of their own.  A range is mapped ONCE: on this
+// stack an address that was un-mapped and mapped again keeps reaching the OLD chunk (igdsp_internal_vmm_remap_check), so a new
+// source always gets a new range.
+struct Source { void *va = nullptr; size_t n = 0; std::vector<size_t> idx; };
+
+struct Explorer {
+    igdsp_ctx *ctx = nullptr;
+    hipStream_t s = nullptr;
+    size_t chunk = 0;
+    hipMemAllocationProp prop{};
+    hipMemAccessDesc acc{};
+    void *cand_va = nullptr;          // scratch address space for probing: slot idx belongs to chunk idx, mapped at most once
+    size_t cand_bytes = 0;
+    bool debug = false;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    std::vector<Chunk> chunks;
+    std::vector<Source> sources;
+    size_t limit_chunks = 0;
+    size_t probe_n = 0;
+    uint32_t probes = 0;
+
+    bool ensure(size_t idx)
+    {
+        while (chunks.size() <= idx) {
+            if (chunks.size() >= limit_chunks) return false;
+            Chunk c;
+            if (hipMemCreate(&c.h, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+            chunks.push_back(c);
+        }
+        return true;
+    }
+    void unmap_scratch(size_t idx)
+    {
+        if (chunks[idx].mapped) { (void)hipMemUnmap((char *)cand_va + idx * chunk, chunk); chunks[idx].mapped = false; }
+    }
+    // time the bare read(src) + record-store(dst) stream: 2 untimed + 4 timed launches
+    bool time_pair(const void *rd, void *dst, float *ms)
+    {
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx), rd, probe_n, dst, s);
+        if (e == hipSuccess) e = hipEventRecord(ea, s);
+        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx), rd, probe_n, dst, s);
+        if (e == hipSuccess) e = hipEventRecord(eb, s);
+        if (e == hipSuccess) e = hipEventSynchronize(eb);
+        float t = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, ea, eb);
+        if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+        *ms = t / 4.f;
+        ++probes;
+        return true;
+    }
+    // time chunk idx as the write side of (source -> chunk); the chunk is mapped on its own scratch slot for that
+    bool probe(size_t idx, const Source &src, float *ms, const char *tag)
+    {
+        char *at = (char *)cand_va + idx * chunk;
+        Chunk &c = chunks[idx];
+        if (c.in_src) return false;
+        if (!c.mapped) {
+            if (hipMemMap(at, chunk, 0, c.h, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+            c.mapped = true;
+            if (hipMemSetAccess(at, chunk, &acc, 1) != hipSuccess) { (void)hipGetLastError(); return false; }
+        }
+        const bool ok = time_pair(src.va, at, ms);
+        if (debug && ok) std::fprintf(stderr, "[igdsp_io] chunk %zu vs %s: %.4f ms\n", idx, tag, *ms);
+        return ok;
+    }
+    // a new probe source from kSrcChunks chunks (each un-mapped from its scratch slot first: one mapping per chunk at a time)
+    bool make_source(const std::vector<size_t> &idx, size_t *which)
+    {
+        Source S;
+        S.n = idx.size();
+        if (hipMemAddressReserve(&S.va, S.n * chunk, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+        sources.push_back(S);
+        Source &T = sources.back();
+        for (size_t k = 0; k < idx.size(); ++k) {
+            unmap_scratch(idx[k]);
+            if (hipMemMap((char *)T.va + k * chunk, chunk, 0, chunks[idx[k]].h, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+            T.idx.push_back(idx[k]);
+            chunks[idx[k]].in_src = true;
+            if (hipMemSetAccess((char *)T.va + k * chunk, chunk, &acc, 1) != hipSuccess) { (void)hipGetLastError(); return false; }
+        }
+        *which = sources.size() - 1;
+        return true;
+    }
+    void drop_source(size_t which)
+    {
+        Source &S = sources[which];
+        for (size_t k = 0; k < S.idx.size(); ++k) { (void)hipMemUnmap((char *)S.va + k * chunk, chunk); chunks[S.idx[k]].in_src = false; }
+        S.idx.clear();                 // the address range stays reserved until cleanup and is never mapped again
+    }
+    void cleanup()
+    {
+        for (size_t i = 0; i < chunks.size(); ++i) unmap_scratch(i);
+        for (size_t w = 0; w < sources.size(); ++w) { drop_source(w); if (sources[w].va) (void)hipMemAddressFree(sources[w].va, sources[w].n * chunk); }
+        sources.clear();
+        for (auto &c : chunks) if (!c.used) (void)hipMemRelease(c.h);
+        chunks.clear();
+        if (ea) (void)hipEventDestroy(ea);
+        if (eb) (void)hipEventDestroy(eb);
+        if (cand_va) (void)hipMemAddressFree(cand_va, cand_bytes);
+        ea = eb = nullptr; cand_va = nullptr;
+        (void)hipGetLastError();
+    }
+};
+
+bool map_chunks(igdsp_io_set::Map &m, size_t chunk, const std::vector<hipMemGenericAllocationHandle_t> &hs, size_t first_slot,
+                const hipMemAccessDesc &acc)
+{
+    for (size_t i = 0; i < hs.size(); ++i) {
+        char *at = (char *)m.va + (first_slot + i) * chunk;
+        if (hipMemMap(at, chunk, 0, hs[i], 0) != hipSuccess) return false;
+        if (hipMemSetAccess(at, chunk, &acc, 1) != hipSuccess) return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int igdsp_io_free(igdsp_ctx *ctx, igdsp_io_set *set)
+{
+    if (!ctx) return IGDSP_EINVAL;
+    if (!set) return IGDSP_OK;
+    (void)hipSetDevice(set->device);
+    (void)hipDeviceSynchronize();
+    for (auto &m : set->maps) {
+        if (!m.va) continue;
+        for (size_t i = 0; i < m.handles.size(); ++i) (void)hipMemUnmap((char *)m.va + i * set->chunk, set->chunk);
+        for (auto h : m.handles) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(m.va, m.bytes);
+    }
+    for (void *p : set->plain) if (p) (void)hipFree(p);
+    (void)hipGetLastError();
+    delete set;
+    return IGDSP_OK;
+}
+
+// Diagnostic (not in include/igdsp.h): does a device address that was un-mapped and then mapped onto ANOTHER chunk reach
+// the new chunk?  Writes 0x11 through address v to chunk X, re-maps v onto chunk Y, writes 0x22 through v, then reads X and Y
+// through fresh addresses.  *x_byte / *y_byte receive the first byte of X / Y (expected 0x11 / 0x22; X == 0x22 means the
+// second write still went to X: a stale translation).  igdsp_io_alloc never re-maps an address, whatever this reports.
+int igdsp_internal_vmm_remap_check(igdsp_ctx *ctx, int *x_byte, int *y_byte)
+{
+    if (!ctx || !x_byte || !y_byte) return IGDSP_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->device;
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    size_t gran = 0;
+    HIP_TRY(ctx, hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    const size_t sz = std::max<size_t>(gran, (size_t)64 << 20);
+    hipMemGenericAllocationHandle_t X, Y;
+    void *v = nullptr, *wx = nullptr, *wy = nullptr;
+    HIP_TRY(ctx, hipMemCreate(&X, sz, &prop, 0));
+    HIP_TRY(ctx, hipMemCreate(&Y, sz, &prop, 0));
+    HIP_TRY(ctx, hipMemAddressReserve(&v, sz, 0, nullptr, 0));
+    HIP_TRY(ctx, hipMemAddressReserve(&wx, sz, 0, nullptr, 0));
+    HIP_TRY(ctx, hipMemAddressReserve(&wy, sz, 0, nullptr, 0));
+    HIP_TRY(ctx, hipMemMap(v, sz, 0, X, 0));
+    HIP_TRY(ctx, hipMemSetAccess(v, sz, &acc, 1));
+    HIP_TRY(ctx, hipMemsetAsync(v, 0x11, sz, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemUnmap(v, sz));
+    HIP_TRY(ctx, hipMemMap(v, sz, 0, Y, 0));
+    HIP_TRY(ctx, hipMemSetAccess(v, sz, &acc, 1));
+    HIP_TRY(ctx, hipMemsetAsync(v, 0x22, sz, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemUnmap(v, sz));
+    HIP_TRY(ctx, hipMemMap(wx, sz, 0, X, 0));
+    HIP_TRY(ctx, hipMemSetAccess(wx, sz, &acc, 1));
+    HIP_TRY(ctx, hipMemMap(wy, sz, 0, Y, 0));
+    HIP_TRY(ctx, hipMemSetAccess(wy, sz, &acc, 1));
+    unsigned char bx = 0, by = 0;
+    HIP_TRY(ctx, hipMemcpy(&bx, (char *)wx + sz / 2, 1, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(&by, (char *)wy + sz / 2, 1, hipMemcpyDeviceToHost));
+    *x_byte = bx; *y_byte = by;
+    (void)hipMemUnmap(wx, sz); (void)hipMemUnmap(wy, sz);
+    (void)hipMemRelease(X); (void)hipMemRelease(Y);
+    (void)hipMemAddressFree(v, sz); (void)hipMemAddressFree(wx, sz); (void)hipMemAddressFree(wy, sz);
+    return IGDSP_OK;
+}
+
+int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t explore_limit_bytes, igdsp_io_set **out_set,
+                   igdsp_io_report *rep)
+{
+    if (!ctx || !bufs || !out_set || n_bufs == 0 || n_bufs > 64) return IGDSP_EINVAL;
+    *out_set = nullptr;
+    igdsp_io_report R;
+    std::memset(&R, 0, sizeof R);
+    for (uint32_t i = 0; i < n_bufs; ++i) {
+        bufs[i].ptr = nullptr;
+        if (bufs[i].bytes == 0 || bufs[i].role > IGDSP_IO_BULK) return IGDSP_EINVAL;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const auto t_start = std::chrono::steady_clock::now();
+    igdsp_io_set *set = new (std::nothrow) igdsp_io_set();
+    if (!set) return IGDSP_ENOMEM;
+    set->device = ctx->device;
+    Explorer X;
+    X.ctx = ctx;
+    X.s = ctx->stream;
+
+    auto finish = [&](int rc) {
+        X.cleanup();
+        R.setup_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+        if (rep) *rep = R;
+        if (rc != IGDSP_OK) { igdsp_io_free(ctx, set); for (uint32_t i = 0; i < n_bufs; ++i) bufs[i].ptr = nullptr; }
+        else *out_set = set;
+        return rc;
+    };
+    auto plain_path = [&]() {                       // consecutive hipMallocs in the order given: what a host would write itself
+        for (uint32_t i = 0; i < n_bufs; ++i) {
+            void *p = nullptr;
+            if (hipMalloc(&p, bufs[i].bytes) != hipSuccess) { (void)hipGetLastError(); return finish(fail(ctx, IGDSP_ENOMEM, "igdsp_io_alloc: hipMalloc")); }
+            set->plain.push_back(p);
+            bufs[i].ptr = p;
+        }
+        return finish(IGDSP_OK);
+    };
+
+    int vmm = 0;
+    if (hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, ctx->device) != hipSuccess) { (void)hipGetLastError(); vmm = 0; }
+    if (const char *e = std::getenv("IGDSP_IO_PLAIN")) if (std::atoi(e) != 0) vmm = 0;
+    if (!vmm) return plain_path();
+
+    X.prop.type = hipMemAllocationTypePinned;
+    X.prop.location.type = hipMemLocationTypeDevice;
+    X.prop.location.id = ctx->device;
+    X.acc.location = X.prop.location;
+    X.acc.flags = hipMemAccessFlagsProtReadWrite;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &X.prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) { (void)hipGetLastError(); return plain_path(); }
+    size_t chunk = (size_t)128 << 20;               // >= the 1/10 of a probe read that a probe launch writes, and small next to the class runs (3-40 GiB)
+    chunk = (chunk + gran - 1) / gran * gran;
+    X.chunk = set->chunk = chunk;
+    R.chunk_bytes = chunk;
+
+    // address ranges + chunk counts per buffer
+    set->maps.resize(n_bufs);
+    std::vector<size_t> nch(n_bufs);
+    size_t in_chunks = 0, in_bytes = 0, rec_chunks = 0, bulk_chunks = 0;
+    for (uint32_t i = 0; i < n_bufs; ++i) {
+        nch[i] = (bufs[i].bytes + chunk - 1) / chunk;
+        auto &m = set->maps[i];
+        m.bytes = nch[i] * chunk;
+        if (hipMemAddressReserve(&m.va, m.bytes, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); m.va = nullptr; return finish(fail(ctx, IGDSP_ENOMEM, "igdsp_io_alloc: hipMemAddressReserve")); }
+        if (bufs[i].role == IGDSP_IO_INPUT) { in_chunks += nch[i]; in_bytes += bufs[i].bytes; }
+        else if (bufs[i].role == IGDSP_IO_RECORD) rec_chunks += nch[i];
+        else bulk_chunks += nch[i];
+    }
+
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    size_t limit = explore_limit_bytes ? explore_limit_bytes : (size_t)(0.6 * (double)free_b);
+    limit = std::min(limit, (size_t)(0.9 * (double)free_b));
+
+    // fresh consecutive chunks for what buffer i still lacks (no class wanted / known)
+    auto map_fresh = [&](uint32_t i) {
+        auto &m = set->maps[i];
+        const size_t have = m.handles.size();
+        std::vector<hipMemGenericAllocationHandle_t> hs;
+        bool ok = true;
+        for (size_t k = have; k < nch[i] && ok; ++k) {
+            hipMemGenericAllocationHandle_t h;
+            ok = hipMemCreate(&h, chunk, &X.prop, 0) == hipSuccess;
+            if (ok) hs.push_back(h);
+        }
+        ok = ok && map_chunks(m, chunk, hs, have, X.acc);
+        m.handles.insert(m.handles.end(), hs.begin(), hs.end());      // owned by the set from here on (released by igdsp_io_free)
+        return ok;
+    };
+
+    // Below 512 MiB of inputs a launch works out of the 256 MiB Infinity Cache and placement does not matter.
+    const bool want_place = in_bytes >= ((size_t)512 << 20) && (rec_chunks + bulk_chunks) > 0 && limit / chunk >= 4 * kSrcChunks;
+    std::vector<size_t> poolA, poolB, poolC;        // chunk indices: class of the inputs / first other class / second other class
+    bool ok = true;
+    if (want_place) {
+        X.probe_n = kSrcChunks * (chunk - 4096) / 10240 * 10240;       // a probe launch reads this much and writes 1/10 of it into the chunk under test
+        X.limit_chunks = limit / chunk;
+        X.cand_bytes = X.limit_chunks * chunk;
+        X.debug = std::getenv("IGDSP_IO_DEBUG") != nullptr;
+        size_t stride = 16;                         // sparse survey: one probe per 2 GiB (classes come in runs of 3-40 GiB of consecutive chunks)
+        if (const char *e = std::getenv("IGDSP_IO_STRIDE")) stride = std::max(1, std::atoi(e));
+        ok = hipMemAddressReserve(&X.cand_va, X.cand_bytes, 0, nullptr, 0) == hipSuccess;
+        ok = ok && hipEventCreate(&X.ea) == hipSuccess && hipEventCreate(&X.eb) == hipSuccess;
+
+        // measured on MI355X: same-class 0.252 ms, other-class 0.219 ms per probe launch (ratio 1.15), spread inside a level < 1 %
+        const float kBimodal = 1.08f, kPure = 1.125f, kNear = 1.035f;
+        size_t srcA = 0, srcB = 0;
+        float tmin = 1e30f, tmax = 0.f;
+        std::vector<size_t> surveyed;
+
+        // source A: ten consecutive chunks; every other chunk is ranked by how fast the stream runs when it writes there
+        auto seed = [&](size_t first) {
+            std::vector<size_t> idx;
+            for (size_t k = 0; k < kSrcChunks; ++k) { if (!X.ensure(first + k)) return false; idx.push_back(first + k); }
+            return X.make_source(idx, &srcA);
+        };
+        auto timeA = [&](size_t idx) {               // time chunk idx against source A (once)
+            Chunk &c = X.chunks[idx];
+            if (c.tA >= 0.f || c.in_src) return true;
+            float t = 0.f;
+            if (!X.probe(idx, X.sources[srcA], &t, "A")) { ok = false; return false; }
+            c.tA = t;
+            return true;
+        };
+        auto survey = [&](bool rescan) {             // every stride-th chunk until two levels are visible and three samples sit on the fast one
+            tmin = 1e30f; tmax = 0.f;
+            std::vector<size_t> todo = rescan ? surveyed : std::vector<size_t>();
+            surveyed.clear();
+            size_t next = 0, seen = 0;
+            for (;;) {
+                size_t idx;
+                if (seen < todo.size()) idx = todo[seen];
+                else { idx = next; if (!X.ensure(idx)) break; }
+                next = std::max(next, idx) + stride;
+                ++seen;
+                if (X.chunks[idx].in_src) continue;
+                if (!timeA(idx)) break;
+                surveyed.push_back(idx);
+                tmin = std::min(tmin, X.chunks[idx].tA); tmax = std::max(tmax, X.chunks[idx].tA);
+                size_t n_fast = 0;
+                for (size_t k : surveyed) if (X.chunks[k].tA < kNear * tmin) ++n_fast;
+                if (seen >= todo.size() && tmax > kBimodal * tmin && n_fast >= 3 && surveyed.size() >= 8) break;
+            }
+        };
+        ok = ok && seed(0);
+        {   // clocks: ~40 ms of the probe stream before anything is compared (the first launches after idle run ~6 % slow)
+            float t = 0.f;
+            if (ok && X.ensure(kSrcChunks)) { for (int k = 0; k < 28 && ok; ++k) ok = X.probe(kSrcChunks, X.sources[srcA], &t, "warm"); }
+        }
+        if (ok) survey(false);
+        if (ok && tmax > kBimodal * tmin && tmax < kPure * tmin) {
+            // The levels are closer than two pure classes give: source A straddles a class boundary.  Re-seed it inside the
+            // longest stretch of survey samples that sit on one level (a run of one class), and time everything again.
+            size_t best_first = 0, best_n = 0;
+            for (size_t a = 0; a < surveyed.size();) {
+                size_t b = a + 1;
+                while (b < surveyed.size() && std::fabs(X.chunks[surveyed[b]].tA - X.chunks[surveyed[a]].tA) < 0.02f * X.chunks[surveyed[a]].tA) ++b;
+                if (b - a > best_n) { best_n = b - a; best_first = surveyed[a]; }
+                a = b;
+            }
+            if (best_n >= 2) {
+                if (X.debug) std::fprintf(stderr, "[igdsp_io] levels %.4f / %.4f: source A is mixed, re-seeding at chunk %zu\n", tmax, tmin, best_first + 2);
+                X.drop_source(srcA);
+                for (auto &c : X.chunks) c.tA = -1.f;
+                ok = seed(best_first + 2);
+                if (ok) survey(true);
+                ++R.reseeds;
+            }
+        }
+        const bool bimodal = ok && tmax > kBimodal * tmin;
+        R.probe_ms_same = tmax;
+        R.probe_ms_other = tmin;
+        if (bimodal) {
+            R.classes_found = 2;
+            const float thr_fast = kNear * tmin, thr_slow = tmax / kNear;
+            auto fast_A = [&](size_t idx) { return !X.chunks[idx].in_src && timeA(idx) && X.chunks[idx].tA < thr_fast; };
+            auto slow_A = [&](size_t idx) { return X.chunks[idx].in_src ? false : (timeA(idx) && X.chunks[idx].tA > thr_slow); };
+            // Walk the chunk sequence from `idx` and collect `want` chunks that satisfy `pred` (which probes on demand): inside
+            // runs that fail, step by `stride` (or to the next chunk that has been timed already); on a hit, walk back over the
+            // chunks skipped since the last probe, then go on densely.
+            std::vector<char> taken;
+            auto walk = [&](size_t idx, size_t want, auto &&pred, std::vector<size_t> &out) {
+                auto take = [&](size_t k) { if (taken.size() <= k) taken.resize(k + 1, 0); if (!taken[k]) { taken[k] = 1; out.push_back(k); } };
+                while (ok && out.size() < want && X.ensure(idx)) {
+                    if (pred(idx)) {
+                        size_t lo = idx;
+                        while (ok && lo > 0 && X.chunks[lo - 1].tA < 0.f && !X.chunks[lo - 1].in_src && pred(lo - 1)) --lo;
+                        for (size_t k = lo; k <= idx && out.size() < want; ++k) take(k);
+                        ++idx;
+                    } else {
+                        size_t nxt = idx + 1;            // skip ahead through un-timed chunks, but stop at one that has been timed already
+                        while (nxt < idx + stride && (nxt >= X.chunks.size() || X.chunks[nxt].tA < 0.f)) ++nxt;
+                        idx = nxt;
+                    }
+                }
+                std::sort(out.begin(), out.end());
+            };
+            // inputs: the chunks of source A themselves plus chunks that write slowly against it (the same class)
+            if (in_chunks > kSrcChunks) walk(0, in_chunks - kSrcChunks, slow_A, poolA);
+            const bool want_spread = bulk_chunks >= 8;
+            walk(0, rec_chunks + bulk_chunks + (want_spread ? kSrcChunks : 0), fast_A, poolB);
+
+            // 2nd split, for bulk outputs: which destinations are fast against the inputs' class AND against the first other
+            // class?  Source B = the first ten pool chunks (consecutive chunks of one run): a chunk that writes slowly against it
+            // shares its class (B), a fast one belongs to the third class (C).  C usually lies tens of GiB further along the
+            // allocation sequence, so the walk continues from where the pool ended until the second halves of the bulk buffers
+            // are covered, or the exploration limit is reached (then B serves both halves).
+            if (ok && want_spread && poolB.size() >= kSrcChunks + rec_chunks + bulk_chunks - bulk_chunks / 2) {
+                const size_t need_c = bulk_chunks / 2;
+                float tbmin = 1e30f, tbmax = 0.f;
+                auto is_C = [&](size_t idx) {
+                    Chunk &c = X.chunks[idx];
+                    if (c.in_src || !fast_A(idx) || !ok) return false;
+                    if (c.tB < 0.f) {
+                        float t = 0.f;
+                        if (!X.probe(idx, X.sources[srcB], &t, "B")) { ok = false; return false; }
+                        c.tB = t;
+                        tbmin = std::min(tbmin, t); tbmax = std::max(tbmax, t);
+                    }
+                    return c.tB < thr_fast;          // the B test streams the same bytes as the A test: same two levels
+                };
+                auto split = [&](const std::vector<size_t> &sb) {
+                    ok = X.make_source(sb, &srcB);
+                    poolC.clear();
+                    tbmin = 1e30f; tbmax = 0.f;
+                    for (size_t k : poolB) if (ok && !X.chunks[k].in_src && is_C(k) && poolC.size() < need_c) poolC.push_back(k);   // every pool chunk gets timed
+                    if (ok && poolC.size() < need_c) {
+                        taken.assign(taken.size(), 0);
+                        for (size_t k : poolC) { if (taken.size() <= k) taken.resize(k + 1, 0); taken[k] = 1; }
+                        walk(poolB.back() + 1, need_c, is_C, poolC);
+                    }
+                    if (X.debug) std::fprintf(stderr, "[igdsp_io] third class: %zu of %zu chunks (levels vs B %.4f / %.4f)\n", poolC.size(), need_c, tbmax, tbmin);
+                    X.drop_source(srcB);
+                };
+                split(std::vector<size_t>(poolB.begin(), poolB.begin() + kSrcChunks));
+                if (ok && poolC.size() < need_c && tbmax > 1.03f * tbmin && tbmax < kPure * tbmin) {
+                    // compressed levels: the ten consecutive chunks of source B mix the two other classes (they can interleave chunk by
+                    // chunk).  Each of the two groups the mixed source separates IS one class: re-seed B from the slower group.
+                    std::vector<size_t> grp;
+                    const float mid = 0.5f * (tbmin + tbmax);
+                    for (size_t k = 0; k < X.chunks.size() && grp.size() < kSrcChunks; ++k)
+                        if (X.chunks[k].tB > mid && X.chunks[k].tA >= 0.f && X.chunks[k].tA < thr_fast) grp.push_back(k);
+                    if (grp.size() == kSrcChunks) {
+                        if (X.debug) std::fprintf(stderr, "[igdsp_io] source B is mixed, re-seeding from the slow group\n");
+                        for (auto &c : X.chunks) c.tB = -1.f;
+                        split(grp);
+                        ++R.reseeds;
+                    }
+                }
+                if (ok && poolC.size() >= std::max<size_t>(4, need_c / 2)) {
+                    R.classes_found = 3;
+                    std::vector<char> is_c(X.chunks.size(), 0);
+                    for (size_t k : poolC) is_c[k] = 1;
+                    // pool B keeps only chunks that are NOT in the third class: timed slow against B, or never timed against it
+                    std::vector<size_t> b;
+                    for (size_t k : poolB) if (!is_c[k] && !(X.chunks[k].tB >= 0.f && X.chunks[k].tB < thr_fast)) b.push_back(k);
+                    poolB = b;
+                } else poolC.clear();
+            }
+            // the inputs get source A's own chunks first
+            if (ok) {
+                std::vector<size_t> a = X.sources[srcA].idx;
+                X.drop_source(srcA);
+                a.insert(a.end(), poolA.begin(), poolA.end());
+                poolA = a;
+            }
+        }
+        R.chunks_explored = (uint32_t)X.chunks.size();
+        R.explored_bytes = (uint64_t)X.chunks.size() * chunk;
+        R.probes = X.probes;
+        (void)hipGetLastError();
+    }
+
+    // Hand the picked chunks to their buffers: INPUT buffers from pool A, RECORD buffers and the first halves of the BULK
+    // buffers from pool B, the second halves from pool C (from B when there is no third class); a pool that runs dry is topped
+    // up from the other output pool, and whatever a buffer still lacks after that comes from fresh consecutive chunks.
+    if (ok && !poolB.empty()) {
+        for (size_t i = 0; i < X.chunks.size(); ++i) X.unmap_scratch(i);
+        size_t a = 0, b = 0, c = 0;
+        bool all = true;
+        const bool spread = !poolC.empty();
+        auto pull = [&](int pool, size_t n, std::vector<hipMemGenericAllocationHandle_t> &hs) {
+            for (size_t k = 0; k < n; ++k) {
+                std::vector<size_t> *p = pool == 0 ? &poolA : (pool == 1 ? &poolB : &poolC);
+                size_t *cur = pool == 0 ? &a : (pool == 1 ? &b : &c);
+                if (*cur >= p->size() && pool != 0) { p = pool == 1 ? &poolC : &poolB; cur = pool == 1 ? &c : &b; }
+                if (*cur >= p->size()) return;
+                X.chunks[(*p)[*cur]].used = true;
+                hs.push_back(X.chunks[(*p)[(*cur)++]].h);
+            }
+        };
+        for (uint32_t role = 0; role < 3 && ok; ++role)
+            for (uint32_t i = 0; i < n_bufs && ok; ++i) {
+                if (bufs[i].role != role) continue;
+                std::vector<hipMemGenericAllocationHandle_t> hs;
+                if (role == IGDSP_IO_INPUT) pull(0, nch[i], hs);
+                else {
+                    const size_t h2 = (role == IGDSP_IO_BULK && spread) ? nch[i] / 2 : 0;  // second-half chunks from class C
+                    pull(1, nch[i] - h2, hs);
+                    if (hs.size() == nch[i] - h2) pull(2, h2, hs);
+                }
+                all = all && hs.size() == nch[i];
+                auto &m = set->maps[i];
+                ok = map_chunks(m, chunk, hs, 0, X.acc);
+                m.handles = hs;
+            }
+        R.placed = (ok && all) ? 1u : 0u;
+        R.bulk_spread = (ok && all && spread && bulk_chunks > 0) ? 1u : 0u;
+    }
+    X.cleanup();                                    // exploration leftovers go back before anything else is allocated
+    for (uint32_t role = 0; role < 3 && ok; ++role)
+        for (uint32_t i = 0; i < n_bufs && ok; ++i)
+            if (bufs[i].role == role && set->maps[i].handles.size() < nch[i]) ok = map_fresh(i);
+    if (!ok) { (void)hipGetLastError(); return finish(fail(ctx, IGDSP_ENOMEM, "igdsp_io_alloc: mapping chunks")); }
+    for (uint32_t i = 0; i < n_bufs; ++i) bufs[i].ptr = set->maps[i].va;
+    return finish(IGDSP_OK);
+}
+
+}  // extern "C"

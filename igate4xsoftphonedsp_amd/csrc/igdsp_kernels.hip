@@ -380,10 +380,12 @@ __device__ __forceinline__ uint4 pack_stats160(uint64_t s, uint32_t peak, uint32
 #endif
 template <bool STORE_PCM>
 __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half, uint4 (&d)[kLoadsPerChunk],
-                                             const uint32_t (&lm)[kLoadsPerChunk], const uint32_t (&pm)[kLoadsPerChunk],
+                                             const uint32_t am, const uint32_t (&fr)[kLoadsPerChunk], const uint32_t (&pm)[kLoadsPerChunk],
                                              const uint32_t off, const uint32_t lane, uint4 *pcm_half, const uint4 *refill,
                                              uint4 *xpose = nullptr)
 {
+    // `am` = the A-law ballot of this half's 32 frames (frame l of the half in bit l); a piece picks its frame's bit with
+    // one v_bfe_i32 when it is expanded, so no per-piece law-mask array stays live across the half (register pressure).
     // `refill` = this lane's first piece of the NEXT super-chunk's same half: piece j's register is
     // reloaded the moment piece j has been folded, so the five loads trickle out evenly and get
     // most of an iteration of lead time.
@@ -393,7 +395,8 @@ __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half
         const int j = u >> 1, k = u & 1;
         wa[k] = (u & 1) ? d[j].z : d[j].x;
         wb[k] = (u & 1) ? d[j].w : d[j].y;
-        const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lm[j], tb = (wb[k] & 0x7F7F7F7Fu) | lm[j];
+        const uint32_t lmj = (uint32_t)__builtin_amdgcn_sbfe(am, fr[j], 1) & 0x80808080u;
+        const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lmj, tb = (wb[k] & 0x7F7F7F7Fu) | lmj;
         e[k][0] = lut_at(lut, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lut, ta, off, 0x0C0C0500u);
         e[k][2] = lut_at(lut, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lut, ta, off, 0x0C0C0700u);
         e[k][4] = lut_at(lut, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lut, tb, off, 0x0C0C0500u);
@@ -547,13 +550,17 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
     const uint32_t n_super = n_frames / kSuperFrames;             // the launcher hands over whole super-chunks only:
     const uint4 *src16 = reinterpret_cast<const uint4 *>(payload); // no tail predicate anywhere in the loop
 
+    // launch-aggregate partials.  Per-lane (VGPR): sum of squares, byte-mean sum, peak.  The three COUNTS are wave-uniform
+    // (every iteration meters 64 frames; silent / clipped come from a ballot + popcount) and live in SGPRs, which keeps
+    // the meter-only kernel inside its 128-VGPR budget without scratch.
     uint64_t a_sumsq = 0;
-    uint32_t a_frames = 0, a_sil = 0, a_clip = 0, a_bm = 0, a_peak = 0;
+    uint32_t a_bm = 0, a_peak = 0;
+    uint32_t u_frames = 0, u_sil = 0, u_clip = 0;
 
     auto fetch_half = [&](uint4 (&dst)[kLoadsPerChunk], uint32_t sidx, uint32_t half) {
-        const uint32_t p0 = sidx * (uint32_t)kStripEntries + half * (uint32_t)kPiecesPerChunk + lane;
+        const uint4 *p0 = src16 + ((uint64_t)sidx * (uint32_t)kStripEntries + half * (uint32_t)kPiecesPerChunk + lane);   // 64-bit piece index
 #pragma unroll
-        for (int j = 0; j < kLoadsPerChunk; ++j) dst[j] = ld_stream(src16 + (p0 + (uint32_t)j * 64u));
+        for (int j = 0; j < kLoadsPerChunk; ++j) dst[j] = ld_stream(p0 + j * 64);
     };
     auto fetch_pt = [&](uint32_t sidx) {                         // codec id (RTP PT) of this lane's own frame
         const uint32_t c = (sidx * (uint32_t)kSuperFrames + lane) % C;     // < 2^32: the ABI caps C*F
@@ -594,19 +601,13 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
             const bool my_alaw = cur_pt == IGDSP_PT_PCMA;
             const uint64_t amask = __ballot(my_alaw);
             const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
-            uint32_t lm0[kLoadsPerChunk], lm1[kLoadsPerChunk];
-#pragma unroll
-            for (int j = 0; j < kLoadsPerChunk; ++j) {
-                lm0[j] = (uint32_t)__builtin_amdgcn_sbfe(am_lo, fr[j], 1) & 0x80808080u;
-                lm1[j] = (uint32_t)__builtin_amdgcn_sbfe(am_hi, fr[j], 1) & 0x80808080u;
-            }
             uint4 *pcm16 = STORE_PCM ? reinterpret_cast<uint4 *>(pcm + (uint64_t)f0 * kFrame) : nullptr;
-            const uint4 *nsrc = src16 + (s_load * (uint32_t)kStripEntries + lane);
+            const uint4 *nsrc = src16 + ((uint64_t)s_load * (uint32_t)kStripEntries + lane);   // 64-bit: 10 pieces per frame pass 2^32 at 68.7 GB
             const uint32_t nxt_pt = fetch_pt(s_load);
             if (DIAG) d_b = now_cycles();
-            process_half<STORE_PCM>(lds, strip, X, lm0, pm, off, lane, pcm16, nsrc, xpose);
+            process_half<STORE_PCM>(lds, strip, X, am_lo, fr, pm, off, lane, pcm16, nsrc, xpose);
             if (DIAG) d_c = now_cycles();
-            process_half<STORE_PCM>(lds, strip + kPiecesPerChunk, Y, lm1, pm, off, lane, pcm16 + 2 * kPiecesPerChunk, nsrc + kPiecesPerChunk, xpose);
+            process_half<STORE_PCM>(lds, strip + kPiecesPerChunk, Y, am_hi, fr, pm, off, lane, pcm16 + 2 * kPiecesPerChunk, nsrc + kPiecesPerChunk, xpose);
             if (DIAG) d_d = now_cycles();
             const uint32_t s_after = has_next ? grab() : 0xFFFFFFFFu;   // its LDS round trip hides under the frame fold below
 
@@ -626,8 +627,10 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
                 uint32_t bm, fl;
                 st_stream(reinterpret_cast<uint4 *>(stats + (f0 + lane)), pack_stats160(s, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl));
                 if (AGG) {
-                    a_sumsq += s << 4; a_frames += 1u; a_sil += (fl & IGDSP_FLAG_SILENT) ? 1u : 0u;
-                    a_clip += (fl & IGDSP_FLAG_CLIPPED) ? 1u : 0u; a_bm += bm; a_peak = max(a_peak, peak);
+                    a_sumsq += s << 4; a_bm += bm; a_peak = max(a_peak, peak);
+                    u_frames += (uint32_t)kSuperFrames;
+                    u_sil += (uint32_t)__builtin_popcountll(__ballot((fl & IGDSP_FLAG_SILENT) != 0u));
+                    u_clip += (uint32_t)__builtin_popcountll(__ballot((fl & IGDSP_FLAG_CLIPPED) != 0u));
                 }
             }
             wave_lds_fence();
@@ -648,9 +651,11 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
         o[7] = __builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID, bits [3:0]
         o[8] = d_rt0; o[9] = __builtin_amdgcn_s_memrealtime(); o[10] = d_red; o[11] = wave;
     }
-    if (AGG && agg != nullptr)   // kernel-argument uniform: every thread of the block takes the same side
-        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kWaves, a_sumsq, (uint64_t)a_frames * kFrame, a_frames,
-                         a_sil, a_clip, a_bm, a_peak);
+    if (AGG && agg != nullptr) {  // kernel-argument uniform: every thread of the block takes the same side
+        const bool l0 = lane == 0u;  // the wave-uniform counts enter the wave reduction once, through lane 0
+        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kWaves, a_sumsq, l0 ? (uint64_t)u_frames * kFrame : 0ull, l0 ? u_frames : 0u,
+                         l0 ? u_sil : 0u, l0 ? u_clip : 0u, a_bm, a_peak);
+    }
 }
 
 // ============================================================================
@@ -688,7 +693,8 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_meter_fat(
     const uint4 *src16 = reinterpret_cast<const uint4 *>(payload);
 
     uint64_t a_sumsq = 0;
-    uint32_t a_frames = 0, a_sil = 0, a_clip = 0, a_bm = 0, a_peak = 0;
+    uint32_t a_bm = 0, a_peak = 0;
+    uint32_t u_frames = 0, u_sil = 0, u_clip = 0;     // wave-uniform counts (SGPRs), as in k_meter_chunk64
 
     uint4 X[kFatDepth][kLoadsPerChunk], Y[kFatDepth][kLoadsPerChunk];
     uint32_t pt[kFatDepth];
@@ -700,7 +706,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_meter_fat(
         for (int s = 0; s < kFatDepth; ++s) {
             const uint32_t i = item_or0((uint32_t)s);
             pt[s] = fetch_pt(i);
-            const uint4 *p0 = src16 + (i * (uint32_t)kStripEntries + lane);
+            const uint4 *p0 = src16 + ((uint64_t)i * (uint32_t)kStripEntries + lane);
 #pragma unroll
             for (int j = 0; j < kLoadsPerChunk; ++j) X[s][j] = ld_stream(p0 + j * 64);
 #pragma unroll
@@ -717,16 +723,10 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_meter_fat(
                 const bool my_alaw = pt[s] == IGDSP_PT_PCMA;
                 const uint64_t amask = __ballot(my_alaw);
                 const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
-                uint32_t lm0[kLoadsPerChunk], lm1[kLoadsPerChunk];
-#pragma unroll
-                for (int j = 0; j < kLoadsPerChunk; ++j) {
-                    lm0[j] = (uint32_t)__builtin_amdgcn_sbfe(am_lo, fr[j], 1) & 0x80808080u;
-                    lm1[j] = (uint32_t)__builtin_amdgcn_sbfe(am_hi, fr[j], 1) & 0x80808080u;
-                }
-                const uint4 *nsrc = src16 + (s_load * (uint32_t)kStripEntries + lane);
+                const uint4 *nsrc = src16 + ((uint64_t)s_load * (uint32_t)kStripEntries + lane);
                 pt[s] = fetch_pt(s_load);
-                process_half<false>(lds, strip, X[s], lm0, pm, off, lane, nullptr, nsrc);
-                process_half<false>(lds, strip + kPiecesPerChunk, Y[s], lm1, pm, off, lane, nullptr, nsrc + kPiecesPerChunk);
+                process_half<false>(lds, strip, X[s], am_lo, fr, pm, off, lane, nullptr, nsrc);
+                process_half<false>(lds, strip + kPiecesPerChunk, Y[s], am_hi, fr, pm, off, lane, nullptr, nsrc + kPiecesPerChunk);
                 wave_lds_fence();
                 {
                     const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kPiecesPerFrame);
@@ -743,8 +743,10 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_meter_fat(
                     uint32_t bm, fl;
                     st_stream(reinterpret_cast<uint4 *>(stats + (f0 + lane)), pack_stats160(sm, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl));
                     if (AGG) {
-                        a_sumsq += sm << 4; a_frames += 1u; a_sil += (fl & IGDSP_FLAG_SILENT) ? 1u : 0u;
-                        a_clip += (fl & IGDSP_FLAG_CLIPPED) ? 1u : 0u; a_bm += bm; a_peak = max(a_peak, peak);
+                        a_sumsq += sm << 4; a_bm += bm; a_peak = max(a_peak, peak);
+                        u_frames += (uint32_t)kSuperFrames;
+                        u_sil += (uint32_t)__builtin_popcountll(__ballot((fl & IGDSP_FLAG_SILENT) != 0u));
+                        u_clip += (uint32_t)__builtin_popcountll(__ballot((fl & IGDSP_FLAG_CLIPPED) != 0u));
                     }
                 }
                 wave_lds_fence();
@@ -752,9 +754,11 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_meter_fat(
             if (done) break;
         }
     }
-    if (AGG && agg != nullptr)
-        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kFatWaves, a_sumsq, (uint64_t)a_frames * kFrame, a_frames,
-                         a_sil, a_clip, a_bm, a_peak);
+    if (AGG && agg != nullptr) {
+        const bool l0 = lane == 0u;
+        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kFatWaves, a_sumsq, l0 ? (uint64_t)u_frames * kFrame : 0ull, l0 ? u_frames : 0u,
+                         l0 ? u_sil : 0u, l0 ? u_clip : 0u, a_bm, a_peak);
+    }
 }
 
 // ============================================================================
@@ -782,11 +786,13 @@ __device__ __forceinline__ uint4 ld16_dw(const uint8_t *p)
 
 // SLOT = true : 192-byte slots (size word + pad + packet at +12), every piece 16-byte aligned.
 // SLOT = false: packets packed at `stride` bytes exactly as received; piece addresses are only dword aligned.
-template <bool SLOT>
+// MIXED: payload pieces of the NEXT item's radio packets (bit fr[j] of `nrm`, that item's radio ballot half) sit 8 bytes
+// further; the offset is formed at refill time so no per-item offset arrays stay live.
+template <bool SLOT, bool MIXED = false>
 __device__ __forceinline__ void rtp_half(const uint2 *lut, uint2 *strip_half, uint4 (&d)[kRtpHalfLoads],
-                                         const uint32_t (&lm)[kRtpHalfLoads], const uint32_t (&pm)[kRtpHalfLoads],
+                                         const uint32_t am, const uint32_t (&fr)[kRtpHalfLoads], const uint32_t (&pm)[kRtpHalfLoads],
                                          const uint32_t (&hs)[kRtpHalfLoads], const uint32_t off, const uint32_t lane,
-                                         const uint8_t *refill_base, const uint32_t (&roff)[kRtpHalfLoads])
+                                         const uint8_t *refill_base, const uint32_t (&roff)[kRtpHalfLoads], const uint32_t nrm = 0u)
 {
     uint2 e[2][8];
     uint32_t wa[2], wb[2];
@@ -794,7 +800,8 @@ __device__ __forceinline__ void rtp_half(const uint2 *lut, uint2 *strip_half, ui
         const int j = u >> 1, k = u & 1;
         wa[k] = (u & 1) ? d[j].z : d[j].x;
         wb[k] = (u & 1) ? d[j].w : d[j].y;
-        const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lm[j], tb = (wb[k] & 0x7F7F7F7Fu) | lm[j];
+        const uint32_t lmj = (uint32_t)__builtin_amdgcn_sbfe(am, fr[j], 1) & 0x80808080u;   // law bit of this piece's packet
+        const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lmj, tb = (wb[k] & 0x7F7F7F7Fu) | lmj;
         e[k][0] = lut_at(lut, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lut, ta, off, 0x0C0C0500u);
         e[k][2] = lut_at(lut, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lut, ta, off, 0x0C0C0700u);
         e[k][4] = lut_at(lut, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lut, tb, off, 0x0C0C0500u);
@@ -821,7 +828,8 @@ __device__ __forceinline__ void rtp_half(const uint2 *lut, uint2 *strip_half, ui
             if (hs[j] == 1u) ent = SLOT ? make_uint2(d[j].x, d[j].w) : make_uint2(0u, d[j].x);
             if (hs[j] == 2u) ent = make_uint2(d[j].z, d[j].w);
             strip_half[j * 64 + lane] = ent;
-            d[j] = SLOT ? ld_stream(reinterpret_cast<const uint4 *>(refill_base + roff[j])) : ld16_dw(refill_base + roff[j]);
+            const uint32_t ro = roff[j] + ((MIXED && hs[j] == 0u) ? ((nrm >> fr[j]) & 1u) * 8u : 0u);
+            d[j] = SLOT ? ld_stream(reinterpret_cast<const uint4 *>(refill_base + ro)) : ld16_dw(refill_base + ro);
             sum = 0; peak = 0; bsum = 0;
         }
     }
@@ -869,6 +877,34 @@ __device__ __forceinline__ void bq_finish(uint32_t *gq, uint32_t G)             
     if (threadIdx.x == 0 && atomicAdd(gq + 1, 1u) == G - 1u) { gq[0] = 0u; gq[1] = 0u; }
 }
 
+// Short payloads in the fused packet kernels.  transport_rtp_cb accepts any payloadlen = size - header
+// (TransportAdapter.cpp:270-291; the hook anticipates 164 and 24, roip_ed137.cpp:6561-6562).  The pipeline above is built
+// for whole 160-byte payloads; a packet with 0 < payloadlen < 160 is rare, so its FRAME LANE re-meters it alone, straight
+// from the packet (L2-hot or re-fetched), with the same LUT: one dword per step, bytes past `len` masked out of every
+// accumulator.  Reads stay inside the packet's slot (len < 160 <= slot payload).  Costs ~25 instructions per dword in the
+// lanes that need it and one wave-uniform branch for everybody else.
+__device__ __forceinline__ void meter_short(const uint2 *lut, const uint32_t off, const uint8_t *pp, const uint32_t len, const bool alaw,
+                                            uint64_t &s, uint32_t &peak, uint32_t &bsum, bool &probe)
+{
+    const uint32_t lm = alaw ? 0x80808080u : 0u;
+    uint64_t acc = 0;
+    uint32_t pk = 0, bs = 0, fail = 0;
+    for (uint32_t i = 0; i < len; i += 4u) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(pp + i);
+        const uint32_t nv = min(len - i, 4u);
+        const uint32_t t = (w & 0x7F7F7F7Fu) | lm;
+        const uint2 e0 = lut_at(lut, t, off, 0x0C0C0400u), e1 = lut_at(lut, t, off, 0x0C0C0500u);
+        const uint2 e2 = lut_at(lut, t, off, 0x0C0C0600u), e3 = lut_at(lut, t, off, 0x0C0C0700u);
+        acc += (uint64_t)(e0.x + (nv > 1u ? e1.x : 0u) + (nv > 2u ? e2.x : 0u) + (nv > 3u ? e3.x : 0u));   // 4 x 2^26 fits u32
+        pk = max(max(pk, e0.y), max(nv > 1u ? e1.y : 0u, max(nv > 2u ? e2.y : 0u, nv > 3u ? e3.y : 0u)));
+        bs = __builtin_amdgcn_sad_u8(nv >= 4u ? w : (w & ((1u << (8u * nv)) - 1u)), 0u, bs);
+        // the reference's silence probe: payload bytes 28 / 38 / 48
+        if (i == 28u || i == 48u) fail |= (w ^ 0xD5u) & 0xFFu;
+        if (i == 36u) fail |= ((w >> 16) ^ 0xD5u) & 0xFFu;
+    }
+    s = acc; peak = pk; bsum = bs; probe = len > 48u && fail == 0u;
+}
+
 // MIXED (packed form only): the header length is per channel, 20 bytes where radio[c] != 0 and 12 elsewhere (SIP and
 // ED-137 legs in one launch, as in the reference's process); `hdr` is then ignored.  The radio flags travel like the
 // codec ids: the frame lanes fetch them one item ahead and a ballot hands every piece its packet's bit.
@@ -912,8 +948,11 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     const uint32_t G = gridDim.x;
     const uint32_t n_super = n_frames / kSuperFrames;
     const uint64_t super_bytes = (uint64_t)kSuperFrames * (SLOT ? (uint32_t)IGDSP_SLOT_BYTES : stride);
+    // launch-aggregate partials: per lane sum of squares, samples (< 2^32 per lane and launch), byte-mean sum, peak; the three
+    // counts are wave-uniform popcounts of ballots and live in SGPRs
     uint64_t a_sumsq = 0;
-    uint32_t a_frames = 0, a_sil = 0, a_clip = 0, a_bm = 0, a_peak = 0;
+    uint32_t a_samp = 0, a_bm = 0, a_peak = 0;
+    uint32_t u_frames = 0, u_sil = 0, u_clip = 0;
 
     auto fetch_radio = [&](uint32_t sidx) { return MIXED ? (uint32_t)radio[(sidx * (uint32_t)kSuperFrames + lane) % C] : 0u; };
     // byte offsets of this lane's pieces for an item whose packets' radio bits are rm: payload pieces of radio packets sit 8 bytes further
@@ -959,12 +998,6 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
             const bool my_alaw = cur_pt == IGDSP_PT_PCMA;
             const uint64_t amask = __ballot(my_alaw);
             const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
-            uint32_t lm0[kRtpHalfLoads], lm1[kRtpHalfLoads];
-#pragma unroll
-            for (int j = 0; j < kRtpHalfLoads; ++j) {
-                lm0[j] = (uint32_t)__builtin_amdgcn_sbfe(am_lo, fr[j], 1) & 0x80808080u;
-                lm1[j] = (uint32_t)__builtin_amdgcn_sbfe(am_hi, fr[j], 1) & 0x80808080u;
-            }
             const uint8_t *nbase = slots + (uint64_t)s_load * super_bytes;
             const uint32_t nxt_pt = fetch_pt(s_load);
             const uint32_t nxt_radio = fetch_radio(s_load);
@@ -973,13 +1006,12 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
             uint32_t my_size = full;
             if (!SLOT && sizes != nullptr) my_size = sizes[f0 + lane];
             if (MIXED) {
-                uint32_t n0[kRtpHalfLoads], n1[kRtpHalfLoads];
-                offsets(__ballot(nxt_radio != 0u), n0, n1);
-                rtp_half<SLOT>(lds, strip, X, lm0, pm, hs, off, lane, nbase, n0);
-                rtp_half<SLOT>(lds, strip + kRtpStrip / 2, Y, lm1, pm, hs, off, lane, nbase, n1);
+                const uint64_t nrm = __ballot(nxt_radio != 0u);
+                rtp_half<SLOT, true>(lds, strip, X, am_lo, fr, pm, hs, off, lane, nbase, roff0, (uint32_t)nrm);
+                rtp_half<SLOT, true>(lds, strip + kRtpStrip / 2, Y, am_hi, fr, pm, hs, off, lane, nbase, roff1, (uint32_t)(nrm >> 32));
             } else {
-                rtp_half<SLOT>(lds, strip, X, lm0, pm, hs, off, lane, nbase, roff0);
-                rtp_half<SLOT>(lds, strip + kRtpStrip / 2, Y, lm1, pm, hs, off, lane, nbase, roff1);
+                rtp_half<SLOT>(lds, strip, X, am_lo, fr, pm, hs, off, lane, nbase, roff0);
+                rtp_half<SLOT>(lds, strip + kRtpStrip / 2, Y, am_hi, fr, pm, hs, off, lane, nbase, roff1);
             }
             const uint32_t s_after = has_next ? grab() : 0xFFFFFFFFu;   // its LDS round trip hides under the fold below
             wave_lds_fence();
@@ -1012,7 +1044,10 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
                     if (plen > (uint32_t)kFrame) hf |= IGDSP_RTP_OVERSIZE;
                     else if ((pt == 0u || pt == 8u) && plen > 0u) hf |= IGDSP_RTP_METERED;
                 }
-                const bool metered = size == full && pt == cur_pt && (pt == 0u || pt == 8u);
+                const bool pt_ok = pt == cur_pt && (pt == 0u || pt == 8u);
+                const bool whole = size == full && pt_ok;
+                const bool shortp = pt_ok && size > hbytes && size < full;           // 0 < payloadlen < 160
+                const bool metered = whole || shortp;
                 const uint32_t fi = f0 + lane;
                 if (info != nullptr) {
                     uint2 rec;
@@ -1022,11 +1057,22 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
                 }
                 uint32_t bm = 0, fl = 0;
                 uint4 rec = make_uint4(0u, 0u, 0u, (uint32_t)IGDSP_FLAG_EMPTY << 24);
-                if (metered) rec = pack_stats160(s, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl);
+                if (whole) rec = pack_stats160(s, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl);
+                if (__ballot(shortp) != 0ull) {           // wave-uniform, rare: see meter_short
+                    if (shortp) {
+                        const uint8_t *pp = slots + (uint64_t)sidx * super_bytes + lane * (SLOT ? (uint32_t)IGDSP_SLOT_BYTES : stride) +
+                                            (SLOT ? (uint32_t)IGDSP_SLOT_PAYLOAD_OFFSET : hbytes);
+                        bool pr;
+                        meter_short(lds, off, pp, plen, my_alaw, s, peak, bsum, pr);
+                        rec = pack_stats(s << 4, peak, bsum, plen, my_alaw, pr, bm, fl);
+                    }
+                }
                 st_stream(reinterpret_cast<uint4 *>(stats + fi), rec);
-                if (AGG && metered) {
-                    a_sumsq += s << 4; a_frames += 1u; a_sil += (fl & IGDSP_FLAG_SILENT) ? 1u : 0u;
-                    a_clip += (fl & IGDSP_FLAG_CLIPPED) ? 1u : 0u; a_bm += bm; a_peak = max(a_peak, peak);
+                if (AGG) {
+                    if (metered) { a_sumsq += s << 4; a_samp += whole ? (uint32_t)kFrame : plen; a_bm += bm; a_peak = max(a_peak, peak); }
+                    u_frames += (uint32_t)__builtin_popcountll(__ballot(metered));
+                    u_sil += (uint32_t)__builtin_popcountll(__ballot(metered && (fl & IGDSP_FLAG_SILENT) != 0u));
+                    u_clip += (uint32_t)__builtin_popcountll(__ballot(metered && (fl & IGDSP_FLAG_CLIPPED) != 0u));
                 }
             }
             wave_lds_fence();
@@ -1038,9 +1084,11 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
         }
     }
     bq_finish(gqueue, G);
-    if (AGG && agg != nullptr)
-        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kRtpWaves, a_sumsq, (uint64_t)a_frames * kFrame, a_frames,
-                         a_sil, a_clip, a_bm, a_peak);
+    if (AGG && agg != nullptr) {
+        const bool l0 = lane == 0u;               // the wave-uniform counts enter the wave reduction once, through lane 0
+        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kRtpWaves, a_sumsq, (uint64_t)a_samp, l0 ? u_frames : 0u,
+                         l0 ? u_sil : 0u, l0 ? u_clip : 0u, a_bm, a_peak);
+    }
 }
 
 // ============================================================================
@@ -1317,6 +1365,27 @@ __global__ __launch_bounds__(256) void k_encode_scalar(const int16_t *__restrict
     }
 }
 
+// Merge one work item's window into hold[c] when several items share a channel (frame segments): device-scope integer
+// atomics (adds, and a CAS loop on the {peak_hold, level_max, level_min} word) — exact and order-independent, so the
+// result is bit-identical to the sequential fold (keeplogAudioLevel, Functions.cpp:2126-2145).
+__device__ __forceinline__ void hold_merge(igdsp_chan_hold *g, const igdsp_chan_hold &h)
+{
+    atomicAdd((unsigned long long *)&g->sumsq_acc, (unsigned long long)h.sumsq_acc);
+    atomicAdd(&g->count, h.count); atomicAdd(&g->level_sum, h.level_sum); atomicAdd(&g->samples, h.samples);
+    atomicAdd(&g->n_silent, h.n_silent); atomicAdd(&g->n_clipped, h.n_clipped);
+    uint32_t *pw = reinterpret_cast<uint32_t *>(&g->peak_hold);
+    uint32_t old = *pw, want;
+    do {
+        const uint32_t pk = max(old & 0xFFFFu, (uint32_t)h.peak_hold), mx = max((old >> 16) & 0xFFu, (uint32_t)h.level_max);
+        const uint32_t mn = min(old >> 24, (uint32_t)h.level_min);
+        want = pk | (mx << 16) | (mn << 24);
+        if (want == old) break;
+        const uint32_t seen = atomicCAS(pw, old, want);
+        if (seen == old) break;
+        old = seen;
+    } while (true);
+}
+
 // ============================================================================
 // Config #5 — fused decode -> stats -> re-encode -> per-channel hold (a1 + a2 + a5 + a6).
 // Channel-group-major: one wavefront owns 64 consecutive CHANNELS and walks all F frames of them
@@ -1440,7 +1509,7 @@ template <int VARIANT>
 __global__ __launch_bounds__(kRtWaves * 64) void k_roundtrip_chunk64(
     const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F,
     uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats, igdsp_chan_hold *__restrict__ hold,
-    const uint8_t *__restrict__ gate, uint32_t n_seg)
+    const uint8_t *__restrict__ gate, uint32_t n_seg, uint32_t n_groups)
 {
     // Work item = (channel group of 64, frame segment): with 65 536 channels there are only 1 024 groups, so the
     // launcher splits the F frames into n_seg segments to fill the chip.  n_seg == 1: the wave owns its channels'
@@ -1463,7 +1532,6 @@ __global__ __launch_bounds__(kRtWaves * 64) void k_roundtrip_chunk64(
         pm[j] = probe_mask(p - fr[j] * 10u);
     }
     const uint32_t total_waves = gridDim.x * kRtWaves;
-    const uint32_t n_groups = C / kSuperFrames;
     const uint32_t fstride16 = C * (uint32_t)kPiecesPerFrame;       // uint4 units between frames of one channel group
 
     for (uint32_t item = wave * gridDim.x + blockIdx.x; item < n_groups * n_seg; item += total_waves) {
@@ -1526,24 +1594,259 @@ __global__ __launch_bounds__(kRtWaves * 64) void k_roundtrip_chunk64(
             wave_lds_fence();
         }
         if (n_seg == 1u) hold[cme] = h;
-        else if (h.count != 0u) {
-            igdsp_chan_hold *g = hold + cme;
-            atomicAdd((unsigned long long *)&g->sumsq_acc, (unsigned long long)h.sumsq_acc);
-            atomicAdd(&g->count, h.count); atomicAdd(&g->level_sum, h.level_sum); atomicAdd(&g->samples, h.samples);
-            atomicAdd(&g->n_silent, h.n_silent); atomicAdd(&g->n_clipped, h.n_clipped);
-            // {u16 peak_hold, u8 level_max, u8 level_min} share one 32-bit word: merge with a CAS loop
-            uint32_t *pw = reinterpret_cast<uint32_t *>(&g->peak_hold);
-            uint32_t old = *pw, want;
-            do {
-                const uint32_t pk = max(old & 0xFFFFu, (uint32_t)h.peak_hold), mx = max((old >> 16) & 0xFFu, (uint32_t)h.level_max);
-                const uint32_t mn = min(old >> 24, (uint32_t)h.level_min);
-                want = pk | (mx << 16) | (mn << 24);
-                if (want == old) break;
-                const uint32_t seen = atomicCAS(pw, old, want);
-                if (seen == old) break;
-                old = seen;
-            } while (true);
+        else if (h.count != 0u) hold_merge(hold + cme, h);
+    }
+}
+
+// ============================================================================
+// Config #5, default form — k_roundtrip_lut64: the same channel-group-major walk as k_roundtrip_chunk64 with the
+// compressor folded INTO the expansion LUT.  A G.711 code has 256 values per law, so decode -> re-encode is a function
+// of (law, code): at kernel start every block evaluates the real expander and the real compressor (enc_uni, the
+// arithmetic igdsp_encode runs) on each of the 2 x 128 magnitudes, once for +|x| and once for -|x|, and stores
+//     entry = { (|x|/4)^2 ,  enc(-|x|) | enc(+|x|) << 8 | |x| << 16 }
+// in the 32-replica conflict-free layout of fill_lut.  Per sample the kernel then does ONE ds_read_b64 (as the meter) and
+// the re-encoded byte is picked by the code's sign bit with v_perm_b32 (3 perms + 2 VALU per 4 samples); the second LDS
+// read per sample of the cell-table form (whose bank conflicts kept the LDS 80 % busy) is gone, and the
+// frame peak comes from max(entry.y) >> 16 (the low bytes only break ties).  mu-law 0x7F ("-0") decodes to PCM 0 and
+// re-encodes as enc(0) = 0xFF, exactly as two's-complement PCM between a real decoder and encoder would.
+// ============================================================================
+#ifndef IGDSP_RTL_WAVES
+#define IGDSP_RTL_WAVES 12
+#endif
+constexpr int kRtlWaves = IGDSP_RTL_WAVES;
+
+template <int VARIANT>
+__device__ __forceinline__ void fill_recode_lut(uint2 *lut)
+{
+    const EncK ku = enc_consts<VARIANT>(false), ka = enc_consts<VARIANT>(true);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kLutEntries; i += blockDim.x) {
+        const uint32_t e = i >> 5;                 // law<<7 | code7
+        const bool alaw = (e & 0x80u) != 0u;
+        const uint32_t ax = alaw ? alaw_abs(e) : ulaw_abs(e);
+        const uint32_t m = ax >> 2;
+        const uint32_t en = enc_uni<VARIANT>(-(int)ax, alaw ? ka : ku), ep = enc_uni<VARIANT>((int)ax, alaw ? ka : ku);
+        lut[i] = make_uint2(m * m, en | (ep << 8) | (ax << 16));
+    }
+}
+
+// One half (32 frames) of a super-chunk: expand, meter, re-encode.  Same software pipeline as process_half (the LUT reads
+// of unit u + 1 are in flight while unit u is folded); the eight re-encoded bytes of a unit are assembled right in its fold.
+__device__ __forceinline__ void recode_half(const uint2 *lut, uint2 *strip_half, uint4 (&d)[kLoadsPerChunk], const uint32_t am,
+                                            const uint32_t (&fr)[kLoadsPerChunk], const uint32_t (&pm)[kLoadsPerChunk],
+                                            const uint32_t off, const uint32_t lane, uint4 *out_half, const uint4 *refill)
+{
+    uint2 e[2][8];
+    uint32_t wa[2], wb[2];
+    auto issue = [&](int u) {
+        const int j = u >> 1, k = u & 1;
+        wa[k] = (u & 1) ? d[j].z : d[j].x;
+        wb[k] = (u & 1) ? d[j].w : d[j].y;
+        const uint32_t lmj = (uint32_t)__builtin_amdgcn_sbfe(am, fr[j], 1) & 0x80808080u;
+        const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lmj, tb = (wb[k] & 0x7F7F7F7Fu) | lmj;
+        e[k][0] = lut_at(lut, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lut, ta, off, 0x0C0C0500u);
+        e[k][2] = lut_at(lut, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lut, ta, off, 0x0C0C0700u);
+        e[k][4] = lut_at(lut, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lut, tb, off, 0x0C0C0500u);
+        e[k][6] = lut_at(lut, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lut, tb, off, 0x0C0C0700u);
+    };
+    // four re-encoded bytes of word w: entries' byte 0 = enc(-|x|), byte 1 = enc(+|x|); a code is positive iff its bit 7 is set
+    auto recode4 = [&](uint32_t w, const uint2 &e0, const uint2 &e1, const uint2 &e2, const uint2 &e3) {
+        const uint32_t p01 = __builtin_amdgcn_perm(e1.y, e0.y, 0x05040100u);       // [e0.neg, e0.pos, e1.neg, e1.pos]
+        const uint32_t p23 = __builtin_amdgcn_perm(e3.y, e2.y, 0x05040100u);
+        const uint32_t sel = ((w >> 7) & 0x01010101u) | 0x06040200u;              // byte i picks pair i, +1 when positive
+        return __builtin_amdgcn_perm(p23, p01, sel);
+    };
+    uint32_t sum = 0, peak = 0, bsum = 0;
+    uint32_t o[4];
+    issue(0);
+#pragma unroll
+    for (int u = 0; u < 2 * kLoadsPerChunk; ++u) {
+        const int j = u >> 1, k = u & 1;
+        if (u + 1 < 2 * kLoadsPerChunk) issue(u + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        bsum = __builtin_amdgcn_sad_u8(wa[k], 0u, bsum);
+        bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
+        sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
+        sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
+        peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);   // |x| << 16 dominates the compare
+        peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
+        o[2 * k] = recode4(wa[k], e[k][0], e[k][1], e[k][2], e[k][3]);
+        o[2 * k + 1] = recode4(wb[k], e[k][4], e[k][5], e[k][6], e[k][7]);
+        if (k == 1) {
+            strip_half[j * 64 + lane] = make_uint2(sum, (peak >> 16) | (bsum << 16) | probe_fail(d[j], pm[j]));
+            st_stream(out_half + j * 64, make_uint4(o[0], o[1], o[2], o[3]));
+            d[j] = ld_stream(refill + j * 64);
+            sum = 0; peak = 0; bsum = 0;
         }
+    }
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_lut64(
+    const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F,
+    uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats, igdsp_chan_hold *__restrict__ hold,
+    const uint8_t *__restrict__ gate, uint32_t n_seg, uint32_t n_groups)
+{
+    // Work item = (group of 64 consecutive channels, segment of the F frames), as in k_roundtrip_chunk64: n_seg == 1 ->
+    // the wave owns hold[c] outright; n_seg > 1 -> windows merge by device-scope integer atomics (exact, order-free).
+    // n_groups = C / 64 channel groups are handled here; channels beyond 64 * n_groups (C % 64) belong to the general kernel.
+    __shared__ uint2 lds[kLutEntries + kRtlWaves * kStripEntries];
+    fill_recode_lut<VARIANT>(lds);
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2 *strip = lds + kLutEntries + wave * kStripEntries;
+    const uint32_t off = (lane & 31u) * 8u;
+    uint32_t fr[kLoadsPerChunk], pm[kLoadsPerChunk];
+#pragma unroll
+    for (int j = 0; j < kLoadsPerChunk; ++j) {
+        const uint32_t p = (uint32_t)j * 64u + lane;
+        fr[j] = p / 10u;
+        pm[j] = probe_mask(p - fr[j] * 10u);
+    }
+    const uint32_t total_waves = gridDim.x * kRtlWaves;
+    const uint32_t fstride16 = C * (uint32_t)kPiecesPerFrame;       // uint4 units between frames of one channel group
+
+    for (uint32_t item = wave * gridDim.x + blockIdx.x; item < n_groups * n_seg; item += total_waves) {
+        const uint32_t seg = item / n_groups, cg = item - seg * n_groups;
+        const uint32_t f_lo = (uint32_t)(((uint64_t)F * seg) / n_seg), f_hi = (uint32_t)(((uint64_t)F * (seg + 1u)) / n_seg);
+        if (f_lo >= f_hi) continue;
+        const uint32_t c0 = cg * kSuperFrames, cme = c0 + lane;
+        const bool my_alaw = codec[cme] == IGDSP_PT_PCMA;
+        const bool open = (gate == nullptr) || (gate[cme] != 0);
+        igdsp_chan_hold h;
+        if (n_seg == 1u) h = hold[cme];
+        else { h.sumsq_acc = 0; h.count = 0; h.level_sum = 0; h.samples = 0; h.peak_hold = 0; h.level_max = 0; h.level_min = 255; h.n_silent = 0; h.n_clipped = 0; }
+        const uint64_t amask = __ballot(my_alaw);
+        const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
+        const uint4 *src = reinterpret_cast<const uint4 *>(payload) + ((uint64_t)c0 * kPiecesPerFrame + lane);
+        uint4 *dst = reinterpret_cast<uint4 *>(out) + ((uint64_t)c0 * kPiecesPerFrame + lane);
+
+        uint4 X[kLoadsPerChunk], Y[kLoadsPerChunk];
+#pragma unroll
+        for (int j = 0; j < kLoadsPerChunk; ++j) X[j] = ld_stream(src + (uint64_t)f_lo * fstride16 + j * 64);
+#pragma unroll
+        for (int j = 0; j < kLoadsPerChunk; ++j) Y[j] = ld_stream(src + (uint64_t)f_lo * fstride16 + kPiecesPerChunk + j * 64);
+
+        for (uint32_t f = f_lo; f < f_hi; ++f) {
+            const bool more = f + 1u < f_hi;                    // wave-uniform; the last frame re-reads itself (cache hit)
+            const uint4 *nsrc = src + (uint64_t)(more ? f + 1u : f) * fstride16;
+            uint4 *o16 = dst + (uint64_t)f * fstride16;
+            recode_half(lds, strip, X, am_lo, fr, pm, off, lane, o16, nsrc);
+            recode_half(lds, strip + kPiecesPerChunk, Y, am_hi, fr, pm, off, lane, o16 + kPiecesPerChunk, nsrc + kPiecesPerChunk);
+            wave_lds_fence();
+            {
+                const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kPiecesPerFrame);
+                uint64_t s = 0;
+                uint32_t peak = 0, bsum = 0, fail = 0;
+#pragma unroll
+                for (int i = 0; i < kPiecesPerFrame / 2; ++i) {
+                    const uint4 v = row[i];
+                    s += (uint64_t)(v.x + v.z);
+                    peak = max(max(peak, v.y & 0x7FFFu), v.w & 0x7FFFu);
+                    bsum += ((v.y >> 16) & 0x7FFFu) + ((v.w >> 16) & 0x7FFFu);
+                    fail |= v.y | v.w;
+                }
+                uint32_t bm, fl;
+                st_stream(reinterpret_cast<uint4 *>(stats + ((uint64_t)f * C + cme)), pack_stats160(s, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl));
+                if (open) {
+                    h.sumsq_acc += s << 4; h.count += 1u; h.level_sum += bm; h.samples += (uint32_t)kFrame;
+                    h.peak_hold = (uint16_t)max((uint32_t)h.peak_hold, peak);
+                    h.level_max = (uint8_t)max((uint32_t)h.level_max, bm);
+                    h.level_min = (uint8_t)min((uint32_t)h.level_min, bm);
+                    h.n_silent += (fl & IGDSP_FLAG_SILENT) ? 1u : 0u;
+                    h.n_clipped += (fl & IGDSP_FLAG_CLIPPED) ? 1u : 0u;
+                }
+            }
+            wave_lds_fence();
+        }
+        if (n_seg == 1u) hold[cme] = h;
+        else if (h.count != 0u) hold_merge(hold + cme, h);
+    }
+}
+
+// ============================================================================
+// Config #5 for every other shape — k_roundtrip_general: one wavefront per CHANNEL walks that channel's F frames
+// (any n in 1..256, any C, unaligned buffers), lane l owning bytes [4l, 4l + 4) of a frame as in
+// k_meter_wave_per_frame.  Decode through the signed 256-entry LUT, stats by wave reduction, re-encode with the full
+// compressor arithmetic (enc_uni) on the decoded PCM, window aggregate in registers, hold[c] written once.  It serves
+// BASELINE config #1's 4 channels, 164- or 24-byte frames, and the C % 64 channels the fused kernel leaves over
+// (channels [c_first, c_first + c_count) of a [F][C][n] batch).
+// ============================================================================
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_roundtrip_general(
+    const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F, uint32_t n,
+    uint32_t c_first, uint32_t c_count, uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats,
+    igdsp_chan_hold *__restrict__ hold, const uint8_t *__restrict__ gate)
+{
+    __shared__ int16_t lut[2][256];
+    for (uint32_t i = threadIdx.x; i < 512u; i += 256u) {
+        const uint32_t code = i & 255u;
+        const int ax = (int)((i >> 8) ? alaw_abs(code) : ulaw_abs(code));
+        lut[i >> 8][code] = (int16_t)((code & 0x80u) ? ax : -ax);
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const bool dword_ok = ((n & 3u) == 0u) && (((reinterpret_cast<uintptr_t>(payload) | reinterpret_cast<uintptr_t>(out)) & 3u) == 0u);
+    const uint32_t b0 = lane * 4u;
+    const uint32_t nvalid = (n > b0) ? min(n - b0, 4u) : 0u;
+    for (uint32_t ci = blockIdx.x * 4u + wave; ci < c_count; ci += gridDim.x * 4u) {
+        const uint32_t c = c_first + ci;
+        const bool alaw = codec[c] == IGDSP_PT_PCMA;
+        const bool open = (gate == nullptr) || (gate[c] != 0);
+        const EncK ek = enc_consts<VARIANT>(alaw);
+        igdsp_chan_hold h = hold[c];                              // wave-uniform copy; lane 0 writes it back
+        auto load_frame = [&](uint32_t f) -> uint32_t {
+            const uint8_t *base = payload + ((uint64_t)f * C + c) * n;
+            uint32_t w = 0;
+            if (dword_ok) { if (b0 < n) w = *reinterpret_cast<const uint32_t *>(base + b0); }
+            else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) if (k < nvalid) w |= (uint32_t)base[b0 + k] << (8u * k);
+            }
+            return w;
+        };
+        uint32_t w = load_frame(0);
+        for (uint32_t f = 0; f < F; ++f) {
+            const uint32_t wn = load_frame(min(f + 1u, F - 1u));  // next frame in flight while this one is folded
+            uint32_t sum = 0, peak = 0, bsum = 0, o = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t b = (w >> (8u * k)) & 255u;
+                const int v = (k < nvalid) ? (int)lut[alaw][b] : 0;
+                const uint32_t ax = (uint32_t)(v < 0 ? -v : v);
+                sum += (ax >> 2) * (ax >> 2);
+                peak = max(peak, ax);
+                bsum += (k < nvalid) ? b : 0u;
+                o |= enc_uni<VARIANT>(v, ek) << (8u * k);        // the compressor on the decoded PCM value
+            }
+            if (b0 < n) {
+                uint8_t *ob = out + ((uint64_t)f * C + c) * n + b0;
+                if (dword_ok) *reinterpret_cast<uint32_t *>(ob) = o;
+                else {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; ++k) if (k < nvalid) ob[k] = (uint8_t)(o >> (8u * k));
+                }
+            }
+            const uint32_t w7 = (uint32_t)__builtin_amdgcn_readlane((int)w, 7), w9 = (uint32_t)__builtin_amdgcn_readlane((int)w, 9),
+                           w12 = (uint32_t)__builtin_amdgcn_readlane((int)w, 12);
+            const bool probe = (n > 48u) && ((w7 & 255u) == 0xD5u) && (((w9 >> 16) & 255u) == 0xD5u) && ((w12 & 255u) == 0xD5u);
+            const uint32_t r_lo = wave_reduce_dpp(sum & 0xFFFFu, OpAdd()), r_hi = wave_reduce_dpp(sum >> 16, OpAdd());
+            const uint64_t s64 = (((uint64_t)r_hi << 16) + r_lo) << 4;
+            peak = wave_reduce_dpp(peak, OpMax());
+            bsum = wave_reduce_dpp(bsum, OpAdd());
+            const igdsp_frame_stats st = make_stats(s64, peak, bsum, n, alaw, probe);
+            if (lane == 0) stats[(uint64_t)f * C + c] = st;
+            if (open) {
+                h.sumsq_acc += s64; h.count += 1u; h.level_sum += st.byte_mean; h.samples += n;
+                h.peak_hold = (uint16_t)max((uint32_t)h.peak_hold, peak);
+                h.level_max = (uint8_t)max((uint32_t)h.level_max, (uint32_t)st.byte_mean);
+                h.level_min = (uint8_t)min((uint32_t)h.level_min, (uint32_t)st.byte_mean);
+                h.n_silent += (st.flags & IGDSP_FLAG_SILENT) ? 1u : 0u;
+                h.n_clipped += (st.flags & IGDSP_FLAG_CLIPPED) ? 1u : 0u;
+            }
+            w = wn;
+        }
+        if (lane == 0) hold[c] = h;
     }
 }
 
@@ -2117,20 +2420,40 @@ hipError_t launch_encode_table(const LaunchCfg &cfg, const int16_t *pcm, const u
     return hipGetLastError();
 }
 
-hipError_t launch_roundtrip(const LaunchCfg &cfg, const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F,
+hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F,
                             uint32_t n, uint8_t *out, igdsp_frame_stats *stats, igdsp_chan_hold *hold,
                             const uint8_t *gate, int variant, hipStream_t s)
 {
     if ((uint64_t)C * F == 0) return hipSuccess;
-    // fill the chip: at least kRtWaves work items per CU; a segment is never shorter than 8 frames
-    const uint32_t n_groups = C / kSuperFrames;
-    const uint32_t want = (uint32_t)cfg.compute_units * kRtWaves;
-    uint32_t n_seg = n_groups >= want ? 1u : (want + n_groups - 1u) / n_groups;
-    n_seg = std::max(1u, std::min(n_seg, std::max(1u, F / 8u)));
-    const uint32_t grid = blocks_for((uint64_t)n_groups * n_seg, kRtWaves, (uint32_t)cfg.compute_units);
-    if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_G191>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg);
-    else                           hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_SUN16>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg);
-    (void)n;
+    // The fused channel-group-major kernels take whole groups of 64 channels of 160-byte frames in 16-byte aligned
+    // buffers; the C % 64 channels left over, and every other shape (n != 160, unaligned buffers), go through
+    // k_roundtrip_general on the same stream.  kernel_variant 4 selects the compressor-cell-table form of the fused
+    // kernel (k_roundtrip_chunk64, kept for A/B runs); the default folds the compressor into the expansion LUT.
+    const bool aligned = ((reinterpret_cast<uintptr_t>(payload) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(stats)) & 15u) == 0u;
+    const uint32_t n_groups = (n == (uint32_t)kFrame && aligned && kernel_variant != 1) ? C / kSuperFrames : 0u;
+    if (n_groups != 0u) {
+        // fill the chip: at least one work item per resident wave; a segment is never shorter than 8 frames
+        const int waves = kernel_variant == 4 ? kRtWaves : kRtlWaves;
+        const uint32_t want = (uint32_t)cfg.compute_units * (uint32_t)waves;
+        uint32_t n_seg = n_groups >= want ? 1u : (want + n_groups - 1u) / n_groups;
+        n_seg = std::max(1u, std::min(n_seg, std::max(1u, F / 8u)));
+        const uint32_t grid = blocks_for((uint64_t)n_groups * n_seg, waves, (uint32_t)cfg.compute_units);
+        if (kernel_variant == 4) {
+            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_G191>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);
+            else                           hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_SUN16>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);
+        } else {
+            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_lut64<IGDSP_ENC_G191>), dim3(grid), dim3(kRtlWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);
+            else                           hipLaunchKernelGGL((k_roundtrip_lut64<IGDSP_ENC_SUN16>), dim3(grid), dim3(kRtlWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t c_first = n_groups * (uint32_t)kSuperFrames, c_count = C - c_first;
+    if (c_count != 0u) {
+        const uint32_t grid = blocks_for(c_count, 4, (uint32_t)cfg.compute_units * 8u);
+        if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_general<IGDSP_ENC_G191>), dim3(grid), dim3(256), 0, s, payload, codec, C, F, n, c_first, c_count, out, stats, hold, gate);
+        else                           hipLaunchKernelGGL((k_roundtrip_general<IGDSP_ENC_SUN16>), dim3(grid), dim3(256), 0, s, payload, codec, C, F, n, c_first, c_count, out, stats, hold, gate);
+    }
     return hipGetLastError();
 }
 

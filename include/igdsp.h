@@ -333,6 +333,50 @@ int igdsp_dev_free(igdsp_ctx *ctx, void *d_ptr);
  * return the probe times of the plain first allocation and of the one kept.  Synchronous; start-up use only. */
 int igdsp_dev_alloc_far(igdsp_ctx *ctx, void **d_ptr, size_t bytes, const void *d_in, size_t in_bytes,
                         uint32_t max_tries, size_t spacer_bytes, float *ms_first, float *ms_kept);
+/* ---- placement-aware allocation of a whole input / output buffer set ---------------------------------------------------
+ * On MI355X a launch that reads one class of device memory and writes another is ~13 % faster than one that reads and
+ * writes the same class, and a bulk write stream spread over the two classes the inputs are NOT in gains another 5-8 %
+ * (igdsp_probe_placement below).  Which class an allocation lands in cannot be queried and differs per
+ * process; consecutive plain allocations normally share one.  igdsp_io_alloc therefore takes the whole buffer set of a
+ * pipeline stage at once, classifies 128 MiB chunks of physical device memory by timing the bare read + record-store
+ * stream against the INPUT buffers, and maps chunks of the right class behind each buffer's (contiguous) address range:
+ *   IGDSP_IO_INPUT   buffers the kernels read (payload ring, packet ring, PCM to encode): consecutive chunks, class "A";
+ *   IGDSP_IO_RECORD  small written outputs (igdsp_frame_stats, igdsp_rtp_info, len, hold): a class other than A;
+ *   IGDSP_IO_BULK    large written outputs (PCM, re-encoded / dense payload): first half in one non-A class, second half
+ *                    in the other (the kernels visit the two halves of a bulk output alternately).
+ * Start-up use: synchronous, takes 0.1-2 s; temporarily holds up to explore_limit_bytes (0 = 60 % of the free device
+ * memory) of chunks while it searches and releases everything it does not hand out.  The pointers stay valid until
+ * igdsp_io_free.  If the virtual-memory API is missing, the largest input is < 512 MiB (the probe then measures the
+ * Infinity Cache, and placement does not matter) or no second class is found, the buffers are still allocated and
+ * report->placed is 0.  Buffer sizes are rounded up to whole chunks internally. */
+#define IGDSP_IO_INPUT   0u
+#define IGDSP_IO_RECORD  1u
+#define IGDSP_IO_BULK    2u
+typedef struct igdsp_io_buf {
+    size_t   bytes;      /* in  */
+    uint32_t role;       /* in: IGDSP_IO_* */
+    uint32_t reserved;
+    void    *ptr;        /* out: device pointer (chunk aligned) */
+} igdsp_io_buf;
+typedef struct igdsp_io_report {
+    uint32_t placed;           /* 1: every RECORD / BULK buffer sits in another class than the inputs                  */
+    uint32_t bulk_spread;      /* 1: BULK buffers have their halves in two different non-input classes                 */
+    uint32_t classes_found;    /* 0 (no probing done), 1, 2 or 3                                                       */
+    uint32_t chunks_explored;  /* chunks created while searching (most are released again)                            */
+    uint32_t probes;           /* timed probe rounds                                                                   */
+    uint32_t reseeds;          /* times the probe source was re-seeded because it straddled a class boundary          */
+    uint64_t chunk_bytes;
+    uint64_t explored_bytes;
+    float    probe_ms_same;    /* bare probe stream (1.25 GiB read + 1/10 written) writing into the class it reads     */
+    float    probe_ms_other;   /* ... writing into another class                                                       */
+    float    setup_ms;         /* host wall time of the call                                                           */
+    float    reserved2;
+} igdsp_io_report;
+typedef struct igdsp_io_set igdsp_io_set;
+int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t explore_limit_bytes,
+                   igdsp_io_set **set, igdsp_io_report *report);
+int igdsp_io_free(igdsp_ctx *ctx, igdsp_io_set *set);
+
 int igdsp_copy_h2d(igdsp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int igdsp_copy_d2h(igdsp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int igdsp_dev_memset(igdsp_ctx *ctx, void *d_ptr, int value, size_t bytes);
@@ -365,7 +409,9 @@ int igdsp_probe_placement(igdsp_ctx *ctx, const void *d_in, size_t bytes, void *
 /* Kernel variant selection for experiments (0 = default tuned path).
  *   1 = one wavefront per channel-frame (40 lanes x dword), the literal north_star mapping
  *   2 = chunk64: one wavefront per 64 consecutive frames, 16 B/lane loads, 16 waves/CU (default for n == 160)
- *   3 = chunk64 with four super-chunks of lookahead per wave, 8 waves/CU (meter-only; experiment) */
+ *   3 = chunk64 with four super-chunks of lookahead per wave, 8 waves/CU (meter-only; experiment)
+ *   4 = igdsp_roundtrip_peakhold through the compressor cell table (k_roundtrip_chunk64, the round-1 form) instead of
+ *       the compressor folded into the expansion LUT; decode_meter as variant 0 */
 int igdsp_set_variant(igdsp_ctx *ctx, int variant);
 
 #ifdef __cplusplus

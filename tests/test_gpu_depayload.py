@@ -172,7 +172,8 @@ def _to_slots(pk180, sizes):
 @pytest.mark.parametrize("C_,F_", [(64, 3), (96, 2), (256, 5), (32, 2)])
 def test_fused_rtp_slots_meter(ctx, orc, C_, F_):
     """igdsp_decode_meter_rtp: one kernel from packet slots to records.  info == the depayload oracle;
-    metered frames (size 180, PT == codec) == the meter oracle; everything else EMPTY; aggregate over metered only."""
+    metered frames (20 < size <= 180, PT == codec; short payloads over their own length) == the meter oracle on the
+    depayload oracle's (payload, len); everything else EMPTY; aggregate over metered only."""
     torch = gu.torch_cuda()
     n = 160
     pk, sizes, _ = _make_packets(orc, C_, F_, 180, n, seed=C_ * 10 + F_)
@@ -187,6 +188,8 @@ def test_fused_rtp_slots_meter(ctx, orc, C_, F_):
             plen = n if kind != 9 else 24
             if kind == 6:
                 plen = 0
+            if kind in (4, 5):
+                plen = int(rng.choice([1, 3, 24, 48, 49, 52, 80, 157, 159]))       # PT matches, 0 < payloadlen < 160: metered over plen bytes
             body = orc.gen_uniform(max(plen, 1), seed=f * 1000 + c).tobytes()[:plen]
             pkt = hu.rtp_packet(pt, f, body, True, int(rng.integers(0, 2 ** 32)))
             pk[f, c, :] = orc.gen_uniform(180, seed=7).astype(np.uint8)       # stale bytes behind short packets
@@ -200,15 +203,16 @@ def test_fused_rtp_slots_meter(ctx, orc, C_, F_):
     ginfo = gu.to_host(d_info, capi.RTP_INFO, (F_, C_))
     for fld in capi.RTP_INFO.names:
         assert np.array_equal(ginfo[fld], einfo[fld]), fld
-    metered = (sizes == 180) & (einfo["pt"] == codec[None, :]) & np.isin(einfo["pt"], (0, 8))
-    assert metered.any() and (~metered).any()
-    est = orc.decode_meter(epl, codec)
+    metered = (sizes > 20) & (sizes <= 180) & (einfo["pt"] == codec[None, :]) & np.isin(einfo["pt"], (0, 8))
+    assert metered.any() and (~metered).any() and (metered & (sizes < 180)).any()
+    est = orc.decode_meter(epl, codec, length=elen)       # short payloads are metered over their own length (TransportAdapter.cpp:270-291)
     gst = gu.to_host(d_st, capi.FRAME_STATS, (F_, C_))
-    gu.assert_stats_equal(gst[metered].reshape(1, -1), est[metered].reshape(1, -1), n=n)
+    gu.assert_stats_equal(gst[metered].reshape(1, -1), est[metered].reshape(1, -1), n=elen[metered].reshape(1, -1))
     emp = gst[~metered]
     assert np.all(emp["flags"] == capi.FLAG_EMPTY) and np.all(emp["sumsq"] == 0) and np.all(emp["peak"] == 0) and np.all(emp["rms"] == 0)
     agg = gu.to_host(d_agg, capi.AGGREGATE)[0]
-    assert int(agg["frames"]) == int(metered.sum()) and int(agg["samples"]) == int(metered.sum()) * n
+    assert int(agg["frames"]) == int(metered.sum()) and int(agg["samples"]) == int(elen[metered].sum())
+    assert int(agg["byte_mean_sum"]) == int(est["byte_mean"][metered].sum()) and int(agg["n_silent"]) == int(((est["flags"] & capi.FLAG_SILENT) != 0)[metered].sum())
     assert int(agg["sumsq"]) == int(est["sumsq"][metered].sum(dtype=np.uint64))
     assert int(agg["peak_slot"][2]) == int(est["peak"][metered].max())
     # shape / alignment rules are reported, not silently re-routed
@@ -234,6 +238,8 @@ def test_fused_packed_packets_meter(ctx, orc, hdr, stride, C_, F_, with_sizes):
             plen = n if kind != 9 else 24
             if kind == 6:
                 plen = 0
+            if kind in (4, 5):
+                plen = int(rng.choice([1, 3, 24, 48, 49, 52, 80, 157, 159]))       # PT matches, 0 < payloadlen < 160: metered over plen bytes
             if not with_sizes and rng.integers(0, 4) == 0:
                 pt = 8 - int(codec[c])                                       # PT mismatch at full size
             body = orc.gen_uniform(max(plen, 1), seed=f * 1000 + c).tobytes()[:plen]
@@ -252,16 +258,18 @@ def test_fused_packed_packets_meter(ctx, orc, hdr, stride, C_, F_, with_sizes):
     ginfo = gu.to_host(d_info, capi.RTP_INFO, (F_, C_))
     for fld in capi.RTP_INFO.names:
         assert np.array_equal(ginfo[fld], einfo[fld]), fld
-    full = (sizes == hdr + n) if with_sizes else np.ones((F_, C_), bool)
+    full = ((sizes > hdr) & (sizes <= hdr + n)) if with_sizes else np.ones((F_, C_), bool)
     metered = full & (einfo["pt"] == codec[None, :]) & np.isin(einfo["pt"], (0, 8))
     assert metered.any() and (~metered).any()
-    est = orc.decode_meter(epl, codec)
+    if with_sizes:
+        assert (metered & (sizes < hdr + n)).any()
+    est = orc.decode_meter(epl, codec, length=elen)
     gst = gu.to_host(d_st, capi.FRAME_STATS, (F_, C_))
-    gu.assert_stats_equal(gst[metered].reshape(1, -1), est[metered].reshape(1, -1), n=n)
+    gu.assert_stats_equal(gst[metered].reshape(1, -1), est[metered].reshape(1, -1), n=elen[metered].reshape(1, -1))
     emp = gst[~metered]
     assert np.all(emp["flags"] == capi.FLAG_EMPTY) and np.all(emp["sumsq"] == 0) and np.all(emp["peak"] == 0)
     agg = gu.to_host(d_agg, capi.AGGREGATE)[0]
-    assert int(agg["frames"]) == int(metered.sum())
+    assert int(agg["frames"]) == int(metered.sum()) and int(agg["samples"]) == int(elen[metered].sum())
     assert int(agg["sumsq"]) == int(est["sumsq"][metered].sum(dtype=np.uint64))
     assert int(agg["peak_slot"][1]) == int(est["peak"][metered].max())
     # packed and slot forms agree record for record on 180-byte radio packets
@@ -298,6 +306,8 @@ def test_fused_packed_packets_mixed_headers(ctx, orc, stride, C_, F_):
             plen = n if kind != 9 else 24
             if kind == 6:
                 plen = 0
+            if kind in (4, 5):
+                plen = int(rng.choice([1, 3, 24, 48, 49, 52, 80, 157, 159]))       # PT matches, 0 < payloadlen < 160: metered over plen bytes
             body = orc.gen_uniform(max(plen, 1), seed=f * 1000 + c).tobytes()[:plen]
             pkt = bytearray(hu.rtp_packet(pt, f, body, bool(radio[c]), int(rng.integers(0, 2 ** 32))))
             if rng.integers(0, 6) == 0:
@@ -312,15 +322,17 @@ def test_fused_packed_packets_mixed_headers(ctx, orc, stride, C_, F_):
     for fld in capi.RTP_INFO.names:
         assert np.array_equal(ginfo[fld], einfo[fld]), fld
     hdrs = np.where(radio, 20, 12)[None, :]
-    metered = (sizes == hdrs + n) & (einfo["pt"] == codec[None, :]) & np.isin(einfo["pt"], (0, 8))
+    metered = (sizes > hdrs) & (sizes <= hdrs + n) & (einfo["pt"] == codec[None, :]) & np.isin(einfo["pt"], (0, 8))
     assert metered[:, radio == 1].any() and metered[:, radio == 0].any() and (~metered).any()
-    est = orc.decode_meter(epl, codec)
+    short = metered & (sizes < hdrs + n)
+    assert short[:, radio == 1].any() and short[:, radio == 0].any()
+    est = orc.decode_meter(epl, codec, length=elen)
     gst = gu.to_host(d_st, capi.FRAME_STATS, (F_, C_))
-    gu.assert_stats_equal(gst[metered].reshape(1, -1), est[metered].reshape(1, -1), n=n)
+    gu.assert_stats_equal(gst[metered].reshape(1, -1), est[metered].reshape(1, -1), n=elen[metered].reshape(1, -1))
     emp = gst[~metered]
     assert np.all(emp["flags"] == capi.FLAG_EMPTY) and np.all(emp["sumsq"] == 0) and np.all(emp["peak"] == 0)
     agg = gu.to_host(d_agg, capi.AGGREGATE)[0]
-    assert int(agg["frames"]) == int(metered.sum())
+    assert int(agg["frames"]) == int(metered.sum()) and int(agg["samples"]) == int(elen[metered].sum())
     assert int(agg["sumsq"]) == int(est["sumsq"][metered].sum(dtype=np.uint64))
     assert int(agg["peak_slot"][3]) == int(est["peak"][metered].max())
     # all-radio through the mixed entry == the single-header entry, record for record

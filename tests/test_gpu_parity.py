@@ -134,7 +134,9 @@ def test_error_codes(ctx):
     assert L.igdsp_decode_meter(ctx.h, d.data_ptr(), d.data_ptr(), None, 4, 1, 160, d.data_ptr(), None, None, 8, None) == -22
     assert L.igdsp_decode_meter(None, d.data_ptr(), d.data_ptr(), None, 4, 1, 160, d.data_ptr(), None, None, 0, None) == -22
     assert L.igdsp_encode(ctx.h, d.data_ptr(), d.data_ptr(), 4, 1, 160, d.data_ptr(), 7, None) == -22
-    assert L.igdsp_roundtrip_peakhold(ctx.h, d.data_ptr(), d.data_ptr(), 33, 1, 160, d.data_ptr(), d.data_ptr(), d.data_ptr(), None, 0, None) == -22
+    assert L.igdsp_roundtrip_peakhold(ctx.h, d.data_ptr(), d.data_ptr(), 33, 1, 160, d.data_ptr(), d.data_ptr(), d.data_ptr(), None, 7, None) == -22   # encoder lineage
+    assert L.igdsp_roundtrip_peakhold(ctx.h, d.data_ptr(), d.data_ptr(), 33, 1, 160, d.data_ptr(), d.data_ptr() + 4, d.data_ptr(), None, 0, None) == -22  # record alignment
+    assert L.igdsp_hold_update(ctx.h, d.data_ptr(), 4, 1, 0, d.data_ptr(), None, None) == -22 and L.igdsp_hold_update(ctx.h, d.data_ptr(), 4, 1, 257, d.data_ptr(), None, None) == -22
     assert L.igdsp_destroy(None) == 0           # NULL tolerated like the reference's setters
     assert L.igdsp_map_call(ctx.h, 1, 1 << 30) == -34
     assert ctx.on_rtp_frame(4242, 0, b"\x00" * 160) == -2      # unmapped call id
@@ -264,6 +266,43 @@ def test_roundtrip_peakhold_vs_oracle(ctx, orc, variant, F_):
     mu = np.broadcast_to((codec == 0)[None, :, None], payload.shape)
     exp[(payload == 0x7F) & mu] = 0xFF
     assert np.array_equal(eout, exp)
+
+
+@pytest.mark.parametrize("kernel", [0, 4])            # 0: compressor folded into the expansion LUT (default); 4: compressor cell table
+@pytest.mark.parametrize("C_,F_,n", [(4, 50, 160), (33, 5, 160), (64, 9, 160), (100, 7, 160), (200, 3, 164), (7, 4, 24), (65, 2, 255),
+                                     (130, 70, 160), (1, 1, 1), (3, 2, 159), (700, 2, 160)])
+def test_roundtrip_every_shape_vs_oracle(ctx, orc, kernel, C_, F_, n):
+    """igdsp_roundtrip_peakhold serves every geometry: whole groups of 64 channels of 160-byte frames through the fused
+    kernel, the C % 64 left-over channels and every other n (164, 24, ... roip_ed137.cpp:6561-6562) / BASELINE config #1's
+    4 channels through the general wave-per-channel kernel; codes, records and hold equal the oracle's, with gates and
+    pre-existing hold state."""
+    torch = gu.torch_cuda()
+    rng = np.random.default_rng(C_ * 1000 + F_ * 10 + n)
+    codec = rng.choice(np.array([0, 8], np.uint8), size=C_)
+    payload = orc.gen_uniform(F_ * C_ * n, seed=C_ + n).reshape(F_, C_, n).copy()
+    payload[0, 0, :] = 0x7F
+    if C_ > 2:
+        payload[F_ - 1, C_ - 1, :] = 0xD5
+        payload[F_ // 2, C_ // 2, :] = rng.choice([0x00, 0x80, 0x2A, 0xAA, 0xFF])
+    gate = (rng.integers(0, 4, C_) != 0).astype(np.uint8)
+    hold0 = gu.new_hold(C_)
+    hold0["peak_hold"][C_ - 1] = 31000
+    hold0["count"][0] = 7
+    hold0["level_min"][0] = 3
+    for variant in (capi.ENC_SUN16, capi.ENC_G191):
+        d_out, d_st, d_hold = gu.dev_zeros(F_ * C_ * n, 0xEE), gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.to_dev(hold0)
+        ctx.set_variant(kernel)
+        try:
+            ctx.roundtrip_peakhold(gu.to_dev(payload), gu.to_dev(codec), C_, F_, n, d_out, d_st, d_hold, gate=gu.to_dev(gate), variant=variant)
+            torch.cuda.synchronize()
+        finally:
+            ctx.set_variant(0)
+        eout, est, ehold = orc.roundtrip_peakhold(payload, codec, hold0.copy().view(orc.CHAN_HOLD), gate=gate, variant=variant)
+        assert np.array_equal(gu.to_host(d_out, np.uint8, (F_, C_, n)), eout)
+        gu.assert_stats_equal(gu.to_host(d_st, capi.FRAME_STATS, (F_, C_)), est, n=n)
+        ghold = gu.to_host(d_hold, capi.CHAN_HOLD)
+        for f in capi.CHAN_HOLD.names:
+            assert np.array_equal(ghold[f], ehold[f]), (f, variant)
 
 
 @pytest.mark.parametrize("variant", [capi.ENC_SUN16, capi.ENC_G191])
