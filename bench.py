@@ -13,12 +13,12 @@ across ranks (weak scaling: 65 536 ch per GPU; N = 8 is BASELINE configs[3], 524
 with ONE 896-byte RCCL all-reduce per launch for the node-wide sum-of-squares / peak,
 issued on a side stream behind the kernel's event.
 
-Before the W warm-up steps the bench (i) repeats the launch for ~60 ms so the clocks settle, and (ii) decides where the
-OUTPUT buffers live: inputs sit at the start of one device arena, the outputs are tried at up to 16 offsets 12 GiB apart
-(and, for modes with a bulk output, across a boundary between two classes of device memory) and the fastest placement
-by timed real launches is kept — on MI355X a launch that reads one class of device memory and writes another is ~13 %
-faster than one that reads and writes the same class (`--placement-positions 1 --prewarm-ms 0` turns
-both off; the choice is reported in config.output_placement).  None of this is inside a step.
+Buffers come from the C ABI: the whole input / output set of the step from ONE igdsp_io_alloc call, which places inputs,
+records and bulk outputs in different classes of device memory (on MI355X a launch that reads one class and writes another
+is ~13 % faster) — this file carries no placement logic of its own.  The same step is ALSO timed on plain
+consecutive igdsp_dev_alloc buffers without any clock pre-warm: `roofline.frac_unassisted` beside `roofline.frac`.
+Before the W warm-up steps of the headline measurement the launch is repeated for ~60 ms so the clocks settle (a gateway
+that runs continuously is always in that state); none of this is inside a step.
 
 Rank 0 prints ONE JSON line; `roofline` is measured live with one pair of HIP events on the launch
 stream around the K timed launches (average launch duration = elapsed / K), `cpu_baseline` is the CPU oracle timed on this box's host cores (N = 1 only).
@@ -57,7 +57,8 @@ def parse():
                     help="strong scaling: this many channels in total, split evenly over the ranks (SURVEY 8d: 524288 over 1/2/4/8 "
                          "GPUs); overrides --channels and reports \"scaling\": \"strong\"")
     ap.add_argument("--mode", choices=["meter", "store", "roundtrip", "depayload", "rtp", "packets", "encode"], default="meter")
-    ap.add_argument("--variant", type=int, default=0, help="0 tuned default, 1 wave-per-frame, 2 chunk32")
+    ap.add_argument("--variant", type=int, default=0,
+                    help="igdsp_set_variant: 0 tuned default, 1 wave-per-frame, 2 chunk64, 3 chunk64 fat waves, 4 round trip through the compressor cell table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on GPUs; gloo only to rehearse the N>1 path on one GPU")
@@ -67,10 +68,12 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="untimed launches of the step before the W warmup steps until this much GPU time has passed: the "
                          "GPU needs ~20 ms of load to reach its steady clocks (first 30 launches measure ~6 %% slow)")
-    ap.add_argument("--placement-positions", type=int, default=16,
-                    help="candidate positions of the OUTPUT buffers, --spacer-gib apart (as many as fit into 80 %% of the free "
-                         "device memory); the fastest (timed real launches) is kept; 1 = off")
-    ap.add_argument("--spacer-gib", type=float, default=12.0)
+    ap.add_argument("--placement", choices=["both", "abi", "plain"], default="both",
+                    help="both: headline on igdsp_io_alloc buffers + the unassisted figure on plain igdsp_dev_alloc buffers; "
+                         "abi / plain: only that one (plain = the headline itself runs on plain buffers)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1 only: bring up a 1-rank nccl (= RCCL) group and run the N > 1 step sequence (kernel -> event -> "
+                         "side-stream all_reduce(int64[112]) -> next launch); reports the per-launch cost against the plain step")
     return ap.parse_args()
 
 
@@ -97,7 +100,7 @@ def cpu_baseline(seconds: float):
     return {
         "value": round(samples / tn / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
         "sample": f"oracle B1 (scalar table decode + u64 sum x^2 + peak + sqrt, -O2) on the first {C_} ch x {F_} frames "
-                  f"of the same D-uniform stream, x{repsn} passes, {cores} pthreads",
+                  f"({samples / 1e6:.0f} MB: cache-resident on the host) of the same D-uniform stream, x{repsn} passes, {cores} pthreads",
         "single_thread_value": round(samples / t1 / 1e6, 2),
         "reference_loop_byte_mean_value": round(samples / tb / 1e6, 2),
         "cpu_model": _cpu_model(), "compiler_flags": "gcc -O2 -funsigned-char (oracle/Makefile; -O2 as the reference's .pro:88)",
@@ -139,6 +142,14 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.backend)
+    elif args.force_collective:
+        import socket
+
+        with socket.socket() as sk:                      # a free local port for the 1-rank rendezvous
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", local))
     if world > capi.AGG_MAX_RANKS:
         raise SystemExit("aggregate vector has 8 peak slots")
 
@@ -156,138 +167,129 @@ def main():
     hs = main_s.cuda_stream
     assert hs != 0
 
-    # ---- one device arena: inputs at its start, the output set at one of --placement-positions offsets behind them.
-    # Where the outputs sit RELATIVE to the inputs matters on MI355X: a stream that reads one ~70 GB
-    # region of device memory and writes another runs ~13 % faster than one that reads and writes the same region.
-    class Arena:
-        def __init__(self, nbytes):
-            self.t = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
-            self.cur = 0
+    # ---- buffers.  Every big buffer of the step comes from the C ABI, twice:
+    #   "plain": igdsp_dev_alloc one after the other, inputs first — what a host writes when it follows the header literally;
+    #   "abi"  : ONE igdsp_io_alloc call for the whole set — the library places inputs / records / bulk outputs in different
+    #            classes of device memory (no search or arena lives in this file any more).
+    # The driver line's `value` / `roofline.frac` are measured on the "abi" set, `roofline.frac_unassisted` on the "plain" one.
+    U8, I16, I64 = torch.uint8, torch.int16, torch.int64
+    MODE = args.mode
+    spec = []                                    # (name, shape, dtype, role)
+    if MODE in ("meter", "store", "roundtrip"):
+        spec.append(("pl", (F_, C_, n), U8, capi.IO_INPUT))
+    if MODE == "depayload":
+        spec.append(("pk", (F_, C_, 180), U8, capi.IO_INPUT))
+    if MODE == "encode":
+        spec.append(("pcm_in", (F_, C_, n), I16, capi.IO_INPUT))
+    if MODE == "rtp":
+        spec.append(("slots", (F_, C_, 192), U8, capi.IO_INPUT))
+    if MODE == "packets":
+        spec.append(("slots", (F_, C_, 180), U8, capi.IO_INPUT))
+    if MODE != "encode":
+        spec.append(("st", (F_ * C_ * 2,), I64, capi.IO_RECORD))               # igdsp_frame_stats[F][C]
+    if MODE in ("rtp", "packets", "depayload"):
+        spec.append(("info", (F_ * C_,), I64, capi.IO_RECORD))
+    if MODE == "depayload":
+        spec.append(("len", (F_ * C_,), I16, capi.IO_RECORD))
+        spec.append(("dense", (F_, C_, n), U8, capi.IO_BULK))
+    if MODE == "store":
+        spec.append(("pcm", (F_, C_, n), I16, capi.IO_BULK))
+    if MODE in ("encode", "roundtrip"):
+        spec.append(("out", (F_, C_, n), U8, capi.IO_BULK))
+    if MODE == "roundtrip":
+        spec.append(("hold", (C_ * 4,), I64, capi.IO_RECORD))
 
-        def take(self, shape, dtype, zero=False):
-            nb = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
-            off = (self.cur + (2 << 20) - 1) & ~((2 << 20) - 1)
-            if off + nb > self.t.numel():
-                raise RuntimeError("bench arena exhausted")
-            self.cur = off + nb
-            v = self.t[off:off + nb].view(dtype).view(shape)
-            if zero:
-                v.zero_()
-            return v
+    def nbytes(shape, dtype):
+        return int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
 
-    positions = max(1, args.placement_positions)
-    spacer = int(args.spacer_gib * (1 << 30))
-    BULK = {"store": "pcm", "depayload": "dense", "encode": "out", "roundtrip": "out"}.get(args.mode)   # the one big output
-    arena = None
-    if positions > 1 and F_ * C_ * n >= (1 << 24):
-        # inputs <= 3 x batch, outputs <= 3 x batch + slack, then one spacer per extra position.  One class of device
-        # memory can be a single run of ~96 GiB, so the search has to reach further than that when the memory is there.
-        fixed = F_ * C_ * n * 8
-        free_b = torch.cuda.mem_get_info()[0]
-        positions = max(1, min(positions, int((0.8 * free_b / max(1, world if args.one_gpu_rehearsal else 1) - fixed) // spacer)))
-        try:
-            arena = Arena(fixed + positions * spacer) if positions > 1 else None
-        except RuntimeError:
-            arena = None                                              # not enough free device memory: plain allocations
-    if arena is None:
-        positions = 1
+    class BufSet:
+        def __init__(self, how):
+            self.how, self.report, self.ioset, self.raw = how, None, None, []
+            sizes = [nbytes(sh, dt) for _, sh, dt, _ in spec]
+            if how == "abi":
+                self.ioset, ptrs, self.report = ctx.io_alloc([(b, role) for b, (_, _, _, role) in zip(sizes, spec)])
+            else:
+                ptrs = [ctx.dev_alloc(b) for b in sizes]
+                self.raw = ptrs
+            self.t = {name: capi.as_tensor(p, b, dt, sh) for p, b, (name, sh, dt, _) in zip(ptrs, sizes, spec)}
+            for name, _, _, role in spec:
+                if role != capi.IO_INPUT:
+                    self.t[name].zero_()
+            self.fill_inputs()
 
-    def new(shape, dtype, zero=False):
-        if arena is not None:
-            return arena.take(shape, dtype, zero)
-        return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device="cuda")
+        def fill_inputs(self):
+            """Synthetic, generated on the device, shard-invariant: this rank holds channels [rank*C, (rank+1)*C) of
+            the global [F][C_total][160] D-uniform array."""
+            t = self.t
+            if "pl" in t:
+                for f in range(F_):
+                    ctx.gen_uniform(t["pl"][f], C_ * n, first_byte=(f * C_total + rank * C_) * n, stream=hs)
+            if "pk" in t:                                                     # [F][C][180] ED-137 packets (header bytes arbitrary but PT 0)
+                ctx.gen_uniform(t["pk"], t["pk"].numel(), seed=7, stream=hs)
+                t["pk"][:, :, 0] = 0x90
+                t["pk"][:, :, 1] = 0
+            if "pcm_in" in t:
+                ctx.gen_uniform(t["pcm_in"], t["pcm_in"].numel() * 2, seed=11, stream=hs)
+            if "slots" in t:
+                ctx.gen_uniform(t["slots"], t["slots"].numel(), seed=7, stream=hs)
+                if MODE == "rtp":                                             # [F][C][192] slots: size 180, PT 0, payload at +32
+                    t["slots"][:, :, 0] = 180
+                    t["slots"][:, :, 1:12] = 0
+                    t["slots"][:, :, 12] = 0x90
+                    t["slots"][:, :, 13] = 0
+                else:                                                         # [F][C][180] ED-137 packets, PT 0, all full
+                    t["slots"][:, :, 0] = 0x90
+                    t["slots"][:, :, 1] = 0
+            if MODE == "roundtrip":                                           # BASELINE configs[4]: mixed A-law / mu-law, D-speech
+                # D-speech (SURVEY 8d): two-tone + noise, amplitude 1000*(1 + c mod 30), encoded with the oracle's encoder.  The
+                # generator is CPU test infrastructure, so a [F][480][160] tile (16 amplitude periods, both laws) is generated once
+                # and replicated across the channels on the device — synthetic data either way.
+                from oracle import oracle as orc
 
-    # ---- inputs.  Synthetic, generated on the device, shard-invariant: this rank holds channels
-    # [rank*C, (rank+1)*C) of the global [F][C_total][160] D-uniform array.
-    d_pl = new((F_, C_, n), torch.uint8)
-    for f in range(F_):
-        first = (f * C_total + rank * C_) * n
-        ctx.gen_uniform(d_pl[f], C_ * n, first_byte=first, stream=hs)
-    d_cd = new((C_,), torch.uint8, zero=True)                             # mu-law (RTP PT 0) everywhere
-    d_pk = d_radio = d_pcm_in = d_slots = None
-    if args.mode == "depayload":                                          # [F][C][180] ED-137 packets (header bytes arbitrary but PT 0)
-        d_pk = new((F_, C_, 180), torch.uint8)
-        ctx.gen_uniform(d_pk, d_pk.numel(), seed=7, stream=hs)
-        d_pk[:, :, 0] = 0x90
-        d_pk[:, :, 1] = 0
-        d_radio = new((C_,), torch.uint8)
-        d_radio.fill_(1)
-    if args.mode == "encode":
-        d_pcm_in = new((F_, C_, n), torch.int16)
-        ctx.gen_uniform(d_pcm_in, d_pcm_in.numel() * 2, seed=11, stream=hs)
-    if args.mode == "rtp":                                                # [F][C][192] slots: size 180, PT 0, payload at +32
-        d_slots = new((F_, C_, 192), torch.uint8)
-        ctx.gen_uniform(d_slots, d_slots.numel(), seed=7, stream=hs)
-        d_slots[:, :, 0] = 180
-        d_slots[:, :, 1:12] = 0
-        d_slots[:, :, 12] = 0x90
-        d_slots[:, :, 13] = 0
-    if args.mode == "packets":                                            # [F][C][180] ED-137 packets, PT 0, all full
-        d_slots = new((F_, C_, 180), torch.uint8)
-        ctx.gen_uniform(d_slots, d_slots.numel(), seed=7, stream=hs)
-        d_slots[:, :, 0] = 0x90
-        d_slots[:, :, 1] = 0
-    if args.mode == "roundtrip":                                          # BASELINE configs[4]: mixed A-law / mu-law, D-speech
+                tile_c = 480
+                tile = orc.gen_speech(tile_c, F_, n, (np.arange(tile_c) & 1).astype(np.uint8) * 8)
+                d_tile = torch.from_numpy(tile).cuda()
+                t["pl"].copy_(d_tile[:, torch.arange(C_, device="cuda") % tile_c, :])
+                del d_tile
+                ctx.hold_reset(t["hold"], C_, stream=hs)
+            torch.cuda.synchronize()
+
+        def close(self):
+            torch.cuda.synchronize()
+            self.t = {}
+            if self.ioset is not None:
+                self.ioset.close()
+            for p in self.raw:
+                ctx.dev_free(p)
+            self.raw = []
+
+    d_cd = torch.zeros((C_,), dtype=U8, device="cuda")                         # mu-law (RTP PT 0) everywhere
+    if MODE == "roundtrip":
         d_cd[1::2] = 8
-        # D-speech: two-tone + noise, amplitude 1000*(1 + c mod 30), encoded with the oracle's encoder.
-        # The generator is CPU test infrastructure, so a [F][480][160] tile (16 amplitude periods, both laws) is
-        # generated once and replicated across the 65 536 channels on the device — synthetic data either way.
-        from oracle import oracle as orc
-
-        tile_c = 480
-        tile = orc.gen_speech(tile_c, F_, n, (np.arange(tile_c) & 1).astype(np.uint8) * 8)
-        d_tile = torch.from_numpy(tile).cuda()
-        d_pl.copy_(d_tile[:, torch.arange(C_, device="cuda") % tile_c, :])
-        del d_tile
-
-    # ---- outputs: everything a launch WRITES.  make_outputs(k) builds the set k spacers behind the inputs.
-    inputs_end = arena.cur if arena is not None else 0
-
-    def make_outputs(k=0, bulk_mid=None):
-        """The output set k spacers behind the inputs; with bulk_mid (arena offset) the bulk output is carved so that
-        its middle sits there (straddling two classes of device memory) and the small outputs follow behind it."""
-        if arena is not None:
-            arena.cur = inputs_end + k * spacer
-        bulk = None
-        if bulk_mid is not None:
-            nb = F_ * C_ * n * (2 if BULK == "pcm" else 1)
-            arena.cur = max(inputs_end, (bulk_mid - nb // 2) & ~((2 << 20) - 1))
-            bulk = new((F_, C_, n), torch.int16 if BULK == "pcm" else torch.uint8)
-        O = {"st": new((F_ * C_ * 2,), torch.int64, zero=True)}          # igdsp_frame_stats[F][C]
-        if args.mode == "store":
-            O["pcm"] = bulk if bulk is not None else new((F_, C_, n), torch.int16)
-        if args.mode in ("rtp", "packets", "depayload"):
-            O["info"] = new((F_ * C_,), torch.int64)
-        if args.mode == "depayload":
-            O["dense"] = bulk if bulk is not None else new((F_, C_, n), torch.uint8)
-            O["len"] = new((F_ * C_,), torch.int16)
-        if args.mode in ("encode", "roundtrip"):
-            O["out"] = bulk if bulk is not None else new((F_, C_, n), torch.uint8)
-        if args.mode == "roundtrip":
-            O["hold"] = new((C_ * 4,), torch.int64, zero=True)
-            ctx.hold_reset(O["hold"], C_, stream=hs)
-        return O
+    d_radio = torch.ones((C_,), dtype=U8, device="cuda")
 
     # one pre-zeroed aggregate per step (896 B each): a launch ADDS into its aggregate, so nothing has to be cleared
     # between launches and, for N > 1, all-reduce k runs on the side stream on its own buffer while launch k + 1 runs
     n_steps_total = args.warmup + args.steps
+    use_coll = world > 1 or args.force_collective
     agg_ring = torch.zeros((n_steps_total, capi.AGG_WORDS), dtype=torch.int64, device="cuda")
-    ev_k = [torch.cuda.Event() for _ in range(n_steps_total)] if world > 1 else []
+    ev_k = [torch.cuda.Event() for _ in range(n_steps_total)] if use_coll else []
     region = ctx.timer()                             # HIP events on the launch stream around the K timed launches
 
-    def launch(agg, O):
-        if args.mode == "encode":
-            ctx.encode(d_pcm_in, d_cd, C_, F_, n, O["out"], stream=hs)
-        elif args.mode == "rtp":
-            ctx.decode_meter_rtp(d_slots, d_cd, C_, F_, O["st"], info=O["info"], agg=agg, rank=rank, stream=hs)
-        elif args.mode == "packets":
-            ctx.decode_meter_packets(d_slots, None, d_cd, C_, F_, 180, 20, O["st"], info=O["info"], agg=agg, rank=rank, stream=hs)
-        elif args.mode == "depayload":
-            ctx.depayload(d_pk, None, d_radio, C_, F_, 180, n, O["dense"], O["len"], O["info"], stream=hs)
-        elif args.mode == "roundtrip":
-            ctx.roundtrip_peakhold(d_pl, d_cd, C_, F_, n, O["out"], O["st"], O["hold"], stream=hs)
+    def launch(agg, B):
+        t = B.t
+        if MODE == "encode":
+            ctx.encode(t["pcm_in"], d_cd, C_, F_, n, t["out"], stream=hs)
+        elif MODE == "rtp":
+            ctx.decode_meter_rtp(t["slots"], d_cd, C_, F_, t["st"], info=t["info"], agg=agg, rank=rank, stream=hs)
+        elif MODE == "packets":
+            ctx.decode_meter_packets(t["slots"], None, d_cd, C_, F_, 180, 20, t["st"], info=t["info"], agg=agg, rank=rank, stream=hs)
+        elif MODE == "depayload":
+            ctx.depayload(t["pk"], None, d_radio, C_, F_, 180, n, t["dense"], t["len"], t["info"], stream=hs)
+        elif MODE == "roundtrip":
+            ctx.roundtrip_peakhold(t["pl"], d_cd, C_, F_, n, t["out"], t["st"], t["hold"], stream=hs)
         else:
-            ctx.decode_meter(d_pl, d_cd, C_, F_, n, O["st"], pcm=O.get("pcm"), agg=None if args.no_agg else agg, rank=rank, stream=hs)
+            ctx.decode_meter(t["pl"], d_cd, C_, F_, n, t["st"], pcm=t.get("pcm"), agg=None if args.no_agg else agg, rank=rank, stream=hs)
 
     def gpu_ms(fn, reps):
         t = ctx.timer()
@@ -299,88 +301,38 @@ def main():
         t.close()
         return ms
 
-    # clock pre-warm (not steps: no collective): repeat the launch until ~prewarm_ms of GPU time has passed
     scratch_agg = torch.zeros((capi.AGG_WORDS,), dtype=torch.int64, device="cuda")
-    OUT = make_outputs(0)
-    spent = 0.0
-    while spent < args.prewarm_ms:
-        spent += 20 * gpu_ms(lambda: launch(scratch_agg, OUT), 20)
 
-    # output placement: candidate k sits k x --spacer-gib behind the inputs; the fastest (timed real launches) is kept
-    placement = None
-    if positions > 1:
-        times = []
-        for k in range(positions):
-            cand = OUT if k == 0 else make_outputs(k)
-            gpu_ms(lambda: launch(scratch_agg, cand), 3)
-            times.append(gpu_ms(lambda: launch(scratch_agg, cand), 10))
-        best = min(range(positions), key=lambda i: times[i])
-        placement = {"positions_ms": [round(x, 4) for x in times], "spacer_GiB": args.spacer_gib, "chosen": best}
-        choice = (times[best], best, None)
-        # Write-heavy modes: a write stream spread over TWO classes of device memory (neither the inputs' class) is
-        # 11-22 % faster than one into a single class (tools/stream_calib2.py); the kernels visit the two halves of
-        # their item range alternately, so a bulk output whose middle sits on a class boundary gets exactly that.
-        # Find such a boundary with the bare-stream probe: label 4 GiB cells A (inputs' class) / B / C, bisect a B|C edge.
-        if BULK is not None:
-            main_in = {"depayload": d_pk, "encode": d_pcm_in}.get(args.mode, d_pl)
-            probe_n = min(main_in.numel() * main_in.element_size(), 1 << 30) & ~15
-            base = arena.t.data_ptr()
-            rec = probe_n // 10 + 4096
+    # ---- the unassisted figure: plain consecutive allocations, no clock pre-warm, W warm-up launches, K timed ones
+    unassisted_ms = None
+    if args.placement in ("both", "plain"):
+        P = BufSet("plain")
+        for _ in range(args.warmup):
+            launch(scratch_agg, P)
+        unassisted_ms = gpu_ms(lambda: launch(scratch_agg, P), args.steps)
+        if args.placement == "both":
+            P.close()
+            del P
+    if args.placement == "plain":
+        OUT = P
+    else:
+        OUT = BufSet("abi")
 
-            def t_pair(src_off, dst_off):               # bare read+record stream: reads arena[src_off..], writes arena[dst_off..]
-                src = main_in if src_off is None else arena.t[src_off:src_off + probe_n]
-                return ctx.probe_placement(src, probe_n, out=arena.t[dst_off:dst_off + rec], reps=4, stream=hs)
-
-            cell = 4 << 30
-            cells = list(range(((inputs_end + cell - 1) // cell) * cell, arena.t.numel() - (2 << 30), cell))
-            t_in = [t_pair(None, c + (1 << 30)) for c in cells]
-            lo, hi = min(t_in), max(t_in)
-            thr = 0.5 * (lo + hi)
-            if hi > 1.06 * lo:                          # both kinds of cell exist
-                not_a = [c for c, t in zip(cells, t_in) if t < thr]
-                ref = not_a[0]
-                label = {ref: "B"}
-                for c in not_a[1:]:
-                    label[c] = "B" if t_pair(ref + (1 << 30), c + (2 << 30)) > thr else "C"
-                edge = next(((c0, c1) for c0, c1 in zip(cells, cells[1:]) if c0 in label and c1 in label and label[c0] != label[c1]), None)
-                if edge is not None:
-                    a_, b_ = edge[0] + (2 << 30), edge[1] + (2 << 30)      # points of known, different labels
-                    la = label[edge[0]]
-                    ref_b = next(c for c in not_a if label[c] == "B")
-                    for _ in range(6):                  # bisect to 64 MiB
-                        mid = ((a_ + b_) // 2) & ~((2 << 20) - 1)
-                        same_as_b = t_pair(ref_b + (1 << 30), mid) > thr if abs(mid - ref_b) > (3 << 30) else None
-                        if same_as_b is None:
-                            break
-                        if ("B" if same_as_b else "C") == la:
-                            a_ = mid
-                        else:
-                            b_ = mid
-                    boundary = (a_ + b_) // 2
-                    cand = make_outputs(best, bulk_mid=boundary)
-                    gpu_ms(lambda: launch(scratch_agg, cand), 3)
-                    t_str = gpu_ms(lambda: launch(scratch_agg, cand), 10)
-                    placement["straddle"] = {"boundary_GiB": round(boundary / 2**30, 2), "ms": round(t_str, 4)}
-                    if t_str < choice[0]:
-                        choice = (t_str, best, boundary)
-        OUT = make_outputs(choice[1], bulk_mid=choice[2])
-        placement["kept"] = "straddle" if choice[2] is not None else "position"
-
-    def step(i: int):
-        agg = agg_ring[i]
+    def step(i: int, coll: bool = True):
+        agg = agg_ring[i] if coll else scratch_agg   # the comparison pass of --force-collective must not add into the ring again
         launch(agg, OUT)
-        if world > 1:                              # node-wide sum / peak: one 896-byte all-reduce per launch, side stream
+        if use_coll and coll:                      # node-wide sum / peak: one 896-byte all-reduce per launch, side stream
             ev_k[i].record(main_s)
             with torch.cuda.stream(comm_s):
                 comm_s.wait_event(ev_k[i])
                 dist.all_reduce(agg, op=dist.ReduceOp.SUM)
 
-    if world > 1:                                  # communicator / channel setup is not part of any step (holds for --warmup 0 too)
+    if use_coll:                                   # communicator / channel setup is not part of any step (holds for --warmup 0 too)
         prime = torch.zeros((capi.AGG_WORDS,), dtype=torch.int64, device="cuda")
         with torch.cuda.stream(comm_s):
             dist.all_reduce(prime, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
-    # the output set may have moved: warm the final configuration right in front of the warm-up steps
+    # clock pre-warm (not steps: no aggregate ring, no collective): the GPU needs ~20 ms of load to reach its steady clocks
     spent = 0.0
     while spent < args.prewarm_ms:
         spent += 20 * gpu_ms(lambda: launch(scratch_agg, OUT), 20)
@@ -408,6 +360,18 @@ def main():
     # average launch duration: the K launches run back to back on `hs`, bracketed by ONE pair of HIP events on that
     # stream (bracketing every launch with its own pair adds ~10 us of event handling to each 0.25 ms launch)
     kern_avg_ms = region.elapsed_ms() / args.steps
+    coll_info = None
+    if args.force_collective and world == 1:
+        # the same K steps again WITHOUT the event + side-stream all-reduce: what the N > 1 sequence costs a launch
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i, coll=False)
+        torch.cuda.synchronize()
+        dt_plain = time.perf_counter() - t1
+        coll_info = {"backend": "nccl (RCCL)", "world": 1, "ms_per_step_with_allreduce": round(dt / args.steps * 1e3, 4),
+                     "ms_per_step_without": round(dt_plain / args.steps * 1e3, 4),
+                     "overhead_frac": round(dt / dt_plain - 1.0, 4), "vector": f"int64[{capi.AGG_WORDS}] on the device, side stream behind the launch's event"}
 
     # node-wide aggregate from the last launch (after the all-reduce every rank holds all peak slots)
     from igate4xsoftphonedsp_amd import dist as igdist
@@ -419,7 +383,7 @@ def main():
     value = total_samples / dt / 1e6
     bps = BYTES_PER_SAMPLE[args.mode]
     achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9
-    kernel_name = "k_encode_lut16" if args.mode == "encode" else "k_meter_rtp64" if args.mode in ("rtp", "packets") else "k_depayload64" if args.mode == "depayload" else "k_roundtrip_chunk64" if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64")
+    kernel_name = "k_encode_lut16" if args.mode == "encode" else "k_meter_rtp64" if args.mode in ("rtp", "packets") else "k_depayload64" if args.mode == "depayload" else ("k_roundtrip_chunk64" if args.variant == 4 else "k_roundtrip_lut64") if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64")
 
     out = {
         "metric": "Msamples/s G.711 decode+RMS, 65536ch@8kHz; %HBM roofline at 1/2/4/8 GPU",
@@ -436,7 +400,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{C_} ch/GPU x {F_} frames x {n} samples {'mixed A-law/mu-law' if args.mode == 'roundtrip' else 'mu-law'} "
-                        f"decode+meter ({args.mode}), device-resident {d_pl.numel() / 1e9:.2f} GB/GPU, "
+                        f"decode+meter ({args.mode}), device-resident {nbytes(spec[0][1], spec[0][2]) / 1e9:.2f} GB/GPU, "
                         f"{'D-speech tile x channels' if args.mode == 'roundtrip' else 'D-uniform seed 0x20241218'}",
             "channels_per_gpu": C_, "channels_total": C_total, "frames_per_launch": F_, "samples_per_frame": n,
             "sharding": "contiguous channel ranges, no data-path collective; one 896 B all-reduce per launch" if world > 1 else "single GPU",
@@ -444,7 +408,10 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "frac_unassisted": None if unassisted_ms is None else round(samples_per_step_rank * bps / (unassisted_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "kernel_avg_ms_unassisted": None if unassisted_ms is None else round(unassisted_ms, 4),
+            "traffic": None,
             "kernel": kernel_name, "kernel_avg_ms": round(kern_avg_ms, 4),
             "algorithmic_bytes_per_sample": round(bps, 5),
             "algorithmic_bytes_per_launch": int(samples_per_step_rank * bps),
@@ -458,50 +425,58 @@ def main():
         import ctypes as CT
 
         sink = torch.zeros((1,), dtype=torch.int64, device="cuda")
+        d_in = OUT.t[spec[0][0]]                        # the mode's main input
+        in_b = d_in.numel() * d_in.element_size()
         tm = ctx.timer()
         for _ in range(3):
-            ctx.stream_read(d_pl, d_pl.numel(), sink, stream=hs)
+            ctx.stream_read(d_in, in_b, sink, stream=hs)
         tm.start(hs)
         for _ in range(10):
-            ctx.stream_read(d_pl, d_pl.numel(), sink, stream=hs)
+            ctx.stream_read(d_in, in_b, sink, stream=hs)
         tm.stop(hs)
-        out["roofline"]["stream_read_GBs"] = round(d_pl.numel() * 10 / (tm.elapsed_ms() * 1e-3) / 1e9, 1)
-        fn = ctx.L.igdsp_internal_stream_rw
-        fn.restype = CT.c_int
-        fn.argtypes = [CT.c_void_p, CT.c_void_p, CT.c_size_t, CT.c_void_p, CT.c_void_p]
-        for _ in range(3):
-            fn(ctx.h, d_pl.data_ptr(), d_pl.numel(), OUT["st"].data_ptr(), hs)
-        tm.start(hs)
-        for _ in range(10):
-            fn(ctx.h, d_pl.data_ptr(), d_pl.numel(), OUT["st"].data_ptr(), hs)
-        tm.stop(hs)
-        rw_ms = tm.elapsed_ms() / 10
-        out["roofline"]["same_traffic_stream_ms"] = round(rw_ms, 4)
-        if args.mode == "meter":
-            out["roofline"]["frac_of_same_traffic_stream"] = round(rw_ms / kern_avg_ms, 4)
+        out["roofline"]["stream_read_GBs"] = round(in_b * 10 / (tm.elapsed_ms() * 1e-3) / 1e9, 1)
+        if "st" in OUT.t and in_b // 10 <= OUT.t["st"].numel() * 8:
+            fn = ctx.L.igdsp_internal_stream_rw
+            fn.restype = CT.c_int
+            fn.argtypes = [CT.c_void_p, CT.c_void_p, CT.c_size_t, CT.c_void_p, CT.c_void_p]
+            for _ in range(3):
+                fn(ctx.h, d_in.data_ptr(), in_b, OUT.t["st"].data_ptr(), hs)
+            tm.start(hs)
+            for _ in range(10):
+                fn(ctx.h, d_in.data_ptr(), in_b, OUT.t["st"].data_ptr(), hs)
+            tm.stop(hs)
+            rw_ms = tm.elapsed_ms() / 10
+            out["roofline"]["same_traffic_stream_ms"] = round(rw_ms, 4)
+            if args.mode == "meter":
+                out["roofline"]["frac_of_same_traffic_stream"] = round(rw_ms / kern_avg_ms, 4)
 
+    # HBM traffic per launch from the PMC counters is NOT measured in this run (counters need rocprofv3 passes of their own):
+    # it is the figure recorded by tools/profile.sh for this mode and shape, labelled with the files it came from
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(traffic_file):
         try:
             with open(traffic_file) as fh:
-                tr = json.load(fh)
-            if tr.get("kernel") == kernel_name and tr.get("channels") == C_ and tr.get("frames") == F_ and tr.get("mode") == args.mode:
+                tr = json.load(fh).get(args.mode)
+            if tr and tr.get("kernel") == kernel_name and tr.get("channels") == C_ and tr.get("frames") == F_:
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = tr.get("source")
         except Exception:
             pass
 
-    if placement:
-        out["config"]["output_placement"] = placement
+    out["config"]["placement"] = {"headline_buffers": OUT.how, "io_alloc_report": OUT.report}
+    if coll_info:
+        out["collective"] = coll_info
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
 
     region.close()
+    OUT.close()
     ctx.close()
     if world > 1:
         dist.barrier()
+    if use_coll:
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))

@@ -1,7 +1,9 @@
 """Multi-GPU sharding helpers.  The path shards trivially by channel (no cross-channel term exists,
 roip_ed137.cpp:6564-6585): rank g owns the contiguous range [g*C/G, (g+1)*C/G) of channels, its own
-payload slab and hold state.  The ONLY collective is one sum all-reduce of the 14-word launch
-aggregate (igdsp_aggregate, include/igdsp.h) — RCCL over xGMI on GPUs (backend "nccl"), gloo in CPU tests."""
+payload slab and hold state.  The ONLY collective is one sum all-reduce of the 112-word (896-byte: seven counters, one
+128-byte line each) launch aggregate (igdsp_aggregate, include/igdsp.h) — RCCL over xGMI on GPUs (backend "nccl"), gloo in
+CPU tests.  Hardware evidence so far: a 1-rank RCCL group on one MI355X (bench.py --force-collective, tests/test_gpu_bench_contract.py);
+N > 1 on real xGMI is only ever run by the driver's 8-GPU scaling bench.  """
 from __future__ import annotations
 
 import math

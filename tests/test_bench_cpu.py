@@ -14,7 +14,7 @@ def _bench(*args):
 def test_help_lists_contract_flags():
     r = _bench("--help")
     assert r.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup", "--channels", "--frames", "--total-channels", "--placement-positions", "--prewarm-ms"):
+    for flag in ("--gpus", "--steps", "--warmup", "--channels", "--frames", "--total-channels", "--placement", "--force-collective", "--prewarm-ms"):
         assert flag in r.stdout, flag
 
 

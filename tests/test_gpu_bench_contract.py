@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--prewarm-ms", "0",
-           "--placement-positions", "1", "--cpu-seconds", "0.5"] + extra
+           "--cpu-seconds", "0.5"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -33,8 +33,10 @@ def test_bench_json_contract_small(orc):
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "u8" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "frac_unassisted", "traffic"):
         assert k in r, k
+    assert r["frac_unassisted"] > 0 and d["config"]["placement"]["headline_buffers"] == "abi"
+    assert d["config"]["placement"]["io_alloc_report"]["placed"] == 0      # 0.3 MB of input: below the size where placement matters
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None                      # the committed PMC figure is for the full-size launch only
@@ -54,3 +56,12 @@ def test_bench_json_contract_small(orc):
 def test_bench_secondary_modes_run(mode):
     d = _run(["--channels", "1024", "--frames", "16", "--mode", mode, "--no-cpu-baseline"])
     assert d["value"] > 0 and d["roofline"]["achieved"] > 0 and d["cpu_baseline"] is None
+
+
+def test_bench_force_collective_runs_rccl_on_one_gpu():
+    """The N > 1 step sequence (kernel -> event -> side-stream all_reduce(int64[112]) over nccl = RCCL -> next launch) on the one
+    GPU of the box, in bench.py's own process: a 1-rank group is brought up before any other GPU work."""
+    d = _run(["--channels", "4096", "--frames", "16", "--force-collective", "--no-cpu-baseline"])
+    c = d["collective"]
+    assert c["world"] == 1 and c["ms_per_step_with_allreduce"] > 0 and c["ms_per_step_without"] > 0
+    assert d["aggregate"]["samples"] == 4096 * 16 * 160
