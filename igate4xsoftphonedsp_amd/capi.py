@@ -20,6 +20,7 @@ ABI_VERSION = 1
 PT_PCMU, PT_PCMA, PT_R2S = 0, 8, 123
 SAMPLES_PER_FRAME = 160
 MAX_PAYLOAD = 256
+STAGE_DEPTH = 8
 ENC_SUN16, ENC_G191 = 0, 1
 FLAG_SILENT, FLAG_PROBE_D5, FLAG_CLIPPED, FLAG_EMPTY = 1, 2, 4, 8
 AGG_MAX_RANKS = 8
@@ -52,7 +53,7 @@ AGGREGATE = np.dtype({      # one 128-byte line per counter (include/igdsp.h); t
 
 class Level(C.Structure):
     _fields_ = [("byte_mean", C.c_uint8), ("flags", C.c_uint8), ("peak", C.c_uint16), ("rms", C.c_float),
-                ("percent", C.c_int32), ("peak_hold", C.c_uint16), ("reserved", C.c_uint16), ("frames", C.c_uint32)]
+                ("percent", C.c_int32), ("peak_hold", C.c_uint16), ("dropped", C.c_uint16), ("frames", C.c_uint32)]
 
 
 IO_INPUT, IO_RECORD, IO_BULK = 0, 1, 2

@@ -20,6 +20,37 @@
 
 using namespace igdsp;
 
+namespace {
+// Layout of the flush upload block (same offsets in the pinned host copy and in its device mirror; every section starts on
+// a 256-byte boundary).  Group A = whole 160-byte frames, dense at stride 160 (the tuned chunk kernel's layout); group B =
+// every other length, slots of 256 bytes with a length per frame (the general kernel).  A "run" = the consecutive records
+// of one channel inside a group: {channel, first record, count}.
+struct UploadLayout { size_t payA, payB, lenB, ptA, ptB, runA, runB, total; };
+inline UploadLayout upload_layout(size_t max_frames, size_t max_channels)
+{
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    UploadLayout L;
+    size_t o = 0;
+    L.payA = o; o = up(o + max_frames * IGDSP_SAMPLES_PER_FRAME);
+    L.payB = o; o = up(o + max_frames * kSlot);
+    L.lenB = o; o = up(o + max_frames * sizeof(uint16_t));
+    L.ptA = o;  o = up(o + max_frames);
+    L.ptB = o;  o = up(o + max_frames);
+    L.runA = o; o = up(o + max_channels * 3 * sizeof(uint32_t));
+    L.runB = o; o = up(o + max_channels * 3 * sizeof(uint32_t));
+    L.total = o;
+    return L;
+}
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield");
+#endif
+}
+}  // namespace
+
 extern "C" {
 
 int igdsp_abi_version(void) { return IGDSP_ABI_VERSION; }
@@ -47,21 +78,24 @@ int igdsp_create(igdsp_ctx **out, int device, uint32_t max_channels)
     for (auto &f : ctx->slot_lock) f.clear();
     ctx->frames_seen.assign(max_channels, 0);
 
-    const size_t slab = (size_t)max_channels * kSlot;
+    ctx->head.assign(max_channels, 0);
+    ctx->tail.assign(max_channels, 0);
+    ctx->frames_dropped.assign(max_channels, 0);
+    ctx->newest.assign(max_channels, 0);
+    const size_t max_frames = (size_t)max_channels * kStageDepth;       // most frames one flush can take
+    const size_t ring = max_frames * kSlot;
+    // upload block: [payload A: max_frames x 160][payload B: max_frames x 256][len B u16][pt A][pt B][runs A: 3 x u32][runs B: 3 x u32]
+    ctx->up_bytes = upload_layout(max_frames, max_channels).total;
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&ctx->h_slab, slab, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&ctx->h_len, max_channels * sizeof(uint16_t), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&ctx->h_pt, max_channels, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&ctx->h_up, slab, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&ctx->h_up_len, max_channels * sizeof(uint16_t), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&ctx->h_up_pt, max_channels, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&ctx->h_ring, ring, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&ctx->h_rlen, max_frames * sizeof(uint16_t), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&ctx->h_rpt, max_frames, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&ctx->h_up, ctx->up_bytes, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_stats, max_channels * sizeof(igdsp_frame_stats), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&ctx->h_fresh, max_channels * sizeof(igdsp_frame_stats), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&ctx->h_fresh, max_frames * sizeof(igdsp_frame_stats), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_hold, max_channels * sizeof(igdsp_chan_hold), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipMalloc((void **)&ctx->d_slab, slab) == hipSuccess;
-    ok = ok && hipMalloc((void **)&ctx->d_len, max_channels * sizeof(uint16_t)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&ctx->d_pt, max_channels) == hipSuccess;
-    ok = ok && hipMalloc((void **)&ctx->d_stats, max_channels * sizeof(igdsp_frame_stats)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_up, ctx->up_bytes) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_stats, max_frames * sizeof(igdsp_frame_stats)) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_hold, max_channels * sizeof(igdsp_chan_hold)) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_queues, kQueueRing * 32u * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(ctx->d_queues, 0, kQueueRing * 32u * sizeof(uint32_t)) == hipSuccess;
@@ -70,8 +104,6 @@ int igdsp_create(igdsp_ctx **out, int device, uint32_t max_channels)
         igdsp_destroy(ctx);
         return IGDSP_ENOMEM;
     }
-    std::memset(ctx->h_len, 0, max_channels * sizeof(uint16_t));
-    std::memset(ctx->h_pt, 0, max_channels);
     std::memset(ctx->h_stats, 0, max_channels * sizeof(igdsp_frame_stats));
     if (launch_hold_reset(ctx->d_hold, max_channels, nullptr, ctx->stream) != hipSuccess ||
         hipMemcpyAsync(ctx->h_hold, ctx->d_hold, max_channels * sizeof(igdsp_chan_hold), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -88,9 +120,9 @@ int igdsp_destroy(igdsp_ctx *ctx)
     if (!ctx) return IGDSP_OK;                       // tolerate NULL like the reference's setters (TransportAdapter.cpp:135-223)
     if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
-    void *hosts[] = {ctx->h_slab, ctx->h_len, ctx->h_pt, ctx->h_up, ctx->h_up_len, ctx->h_up_pt, ctx->h_stats, ctx->h_fresh, ctx->h_hold};
+    void *hosts[] = {ctx->h_ring, ctx->h_rlen, ctx->h_rpt, ctx->h_up, ctx->h_stats, ctx->h_fresh, ctx->h_hold};
     for (void *p : hosts) if (p) (void)hipHostFree(p);
-    void *devs[] = {ctx->d_slab, ctx->d_len, ctx->d_pt, ctx->d_stats, ctx->d_hold, ctx->d_queues};
+    void *devs[] = {ctx->d_up, ctx->d_stats, ctx->d_hold, ctx->d_queues};
     for (void *p : devs) if (p) (void)hipFree(p);
     delete ctx;
     return IGDSP_OK;
@@ -150,14 +182,22 @@ int igdsp_on_rtp_frame(igdsp_ctx *ctx, int32_t call_id, uint8_t pt, const uint8_
     if (ch == kNoChan) return IGDSP_ENOENT;          // the reference's if-chain falls through silently; we report it
     if (payloadlen == 0) return IGDSP_OK;
     std::atomic_flag &lk = ctx->slot_lock[ch];
-    while (lk.test_and_set(std::memory_order_acquire)) { /* held only for one 160-byte copy */ }
-    std::memcpy(ctx->h_slab + (size_t)ch * kSlot, payload, payloadlen);
-    ctx->h_len[ch] = (uint16_t)payloadlen;
-    ctx->h_pt[ch] = pt;
+    while (lk.test_and_set(std::memory_order_acquire)) cpu_relax();     // held by another producer / the flush for one <= 256-byte copy
+    int rc = IGDSP_OK;
+    if (ctx->head[ch] - ctx->tail[ch] == kStageDepth) {                 // the owner thread is > 160 ms late: the oldest frame goes
+        ctx->tail[ch] += 1;
+        ctx->frames_dropped[ch] += 1;
+        rc = IGDSP_EBUSY;
+    }
+    const size_t slot = (size_t)ch * kStageDepth + (ctx->head[ch] % kStageDepth);
+    std::memcpy(ctx->h_ring + slot * kSlot, payload, payloadlen);
+    ctx->h_rlen[slot] = (uint16_t)payloadlen;
+    ctx->h_rpt[slot] = pt;
+    ctx->head[ch] += 1;
     lk.clear(std::memory_order_release);
     uint32_t hw = ctx->hi_water.load(std::memory_order_relaxed);
     while (hw < ch + 1 && !ctx->hi_water.compare_exchange_weak(hw, ch + 1, std::memory_order_relaxed)) {}
-    return IGDSP_OK;
+    return rc;
 }
 
 int igdsp_flush(igdsp_ctx *ctx, uint32_t *n_frames_out)
@@ -166,33 +206,75 @@ int igdsp_flush(igdsp_ctx *ctx, uint32_t *n_frames_out)
     std::lock_guard<std::mutex> g(ctx->flush_mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t nch = ctx->hi_water.load(std::memory_order_relaxed);
-    uint32_t staged = 0;
+    const size_t max_frames = (size_t)ctx->max_channels * kStageDepth;
+    const UploadLayout L = upload_layout(max_frames, ctx->max_channels);
+    uint8_t *up = ctx->h_up;
+    uint16_t *lenB = reinterpret_cast<uint16_t *>(up + L.lenB);
+    uint32_t *runA = reinterpret_cast<uint32_t *>(up + L.runA), *runB = reinterpret_cast<uint32_t *>(up + L.runB);
+    // 1. snapshot every channel's staged frames (oldest first) into the upload block, compacted, under the channel's flag
+    uint32_t nA = 0, nB = 0, nrA = 0, nrB = 0;
+    constexpr uint32_t kNone = 0xFFFFFFFFu, kB = 0x80000000u;
     for (uint32_t c = 0; c < nch; ++c) {
         std::atomic_flag &lk = ctx->slot_lock[c];
-        while (lk.test_and_set(std::memory_order_acquire)) {}
-        const uint16_t l = ctx->h_len[c];
-        ctx->h_up_len[c] = l;
-        ctx->h_up_pt[c] = ctx->h_pt[c];
-        if (l) { std::memcpy(ctx->h_up + (size_t)c * kSlot, ctx->h_slab + (size_t)c * kSlot, l); ctx->h_len[c] = 0; }
+        while (lk.test_and_set(std::memory_order_acquire)) cpu_relax();
+        const uint32_t t0 = ctx->tail[c], h0 = ctx->head[c];
+        uint32_t a0 = nA, b0 = nB, newest = kNone;
+        for (uint32_t k = t0; k != h0; ++k) {
+            const size_t slot = (size_t)c * kStageDepth + (k % kStageDepth);
+            const uint16_t l = ctx->h_rlen[slot];
+            if (l == IGDSP_SAMPLES_PER_FRAME) {
+                std::memcpy(up + L.payA + (size_t)nA * IGDSP_SAMPLES_PER_FRAME, ctx->h_ring + slot * kSlot, l);
+                up[L.ptA + nA] = ctx->h_rpt[slot];
+                newest = nA++;
+            } else {
+                std::memcpy(up + L.payB + (size_t)nB * kSlot, ctx->h_ring + slot * kSlot, l);
+                lenB[nB] = l;
+                up[L.ptB + nB] = ctx->h_rpt[slot];
+                newest = kB | nB++;
+            }
+        }
+        ctx->tail[c] = h0;
         lk.clear(std::memory_order_release);
-        if (l) { ++staged; ctx->frames_seen[c] += 1; }
+        if (nA != a0) { runA[3 * nrA] = c; runA[3 * nrA + 1] = a0; runA[3 * nrA + 2] = nA - a0; ++nrA; }
+        if (nB != b0) { runB[3 * nrB] = c; runB[3 * nrB + 1] = b0; runB[3 * nrB + 2] = nB - b0; ++nrB; }
+        ctx->newest[c] = newest;
+        ctx->frames_seen[c] += h0 - t0;
     }
+    const uint32_t staged = nA + nB;
     if (n_frames_out) *n_frames_out = staged;
-    if (nch == 0 || staged == 0) return IGDSP_OK;
+    if (staged == 0) return IGDSP_OK;
+    // 2. one upload (everything up to the last used section; the block is ~1.7 KB per staged frame at most), meter, fold, download
     hipStream_t s = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slab, ctx->h_up, (size_t)nch * kSlot, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_len, ctx->h_up_len, nch * sizeof(uint16_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pt, ctx->h_up_pt, nch, hipMemcpyHostToDevice, s));
-    // one frame per channel, slot width 256, ragged lengths -> the general wave-per-frame kernel
-    HIP_TRY(ctx, launch_decode_meter(cfg_of(ctx), 1, ctx->d_slab, ctx->d_pt, ctx->d_len, nch, 1, kSlot, ctx->d_stats, nullptr, nullptr, 0, s));
-    HIP_TRY(ctx, launch_hold_update(ctx->d_stats, ctx->d_len, nch, 1, kSlot, ctx->d_hold, nullptr, s));
-    // a channel with nothing staged keeps its previous level: copy to a scratch and merge on the host
-    igdsp_frame_stats *fresh = ctx->h_fresh;
-    HIP_TRY(ctx, hipMemcpyAsync(fresh, ctx->d_stats, nch * sizeof(igdsp_frame_stats), hipMemcpyDeviceToHost, s));
+    uint8_t *d = ctx->d_up;
+    auto copy_section = [&](size_t off, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpyAsync(d + off, up + off, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+    };
+    HIP_TRY(ctx, copy_section(L.payA, (size_t)nA * IGDSP_SAMPLES_PER_FRAME));
+    HIP_TRY(ctx, copy_section(L.payB, (size_t)nB * kSlot));
+    HIP_TRY(ctx, copy_section(L.lenB, (size_t)nB * sizeof(uint16_t)));
+    HIP_TRY(ctx, copy_section(L.ptA, nA));
+    HIP_TRY(ctx, copy_section(L.ptB, nB));
+    HIP_TRY(ctx, copy_section(L.runA, (size_t)nrA * 3 * sizeof(uint32_t)));
+    HIP_TRY(ctx, copy_section(L.runB, (size_t)nrB * 3 * sizeof(uint32_t)));
+    // records: group A first, then group B.  Each staged frame is its own "channel" of a one-frame batch (its codec = its PT).
+    igdsp_frame_stats *stA = ctx->d_stats, *stB = ctx->d_stats + nA;
+    if (nA) {   // whole 160-byte frames, dense: the chunk kernel takes every 64, the general kernel the < 64 left over
+        HIP_TRY(ctx, launch_decode_meter(cfg_of(ctx), 0, d + L.payA, d + L.ptA, nullptr, nA, 1, IGDSP_SAMPLES_PER_FRAME, stA, nullptr, nullptr, 0, s));
+        HIP_TRY(ctx, launch_hold_fold_runs(stA, nullptr, IGDSP_SAMPLES_PER_FRAME, reinterpret_cast<const uint32_t *>(d + L.runA), nrA, ctx->d_hold, s));
+    }
+    if (nB) {   // every other length: 256-byte slots with a length per frame
+        HIP_TRY(ctx, launch_decode_meter(cfg_of(ctx), 1, d + L.payB, d + L.ptB, reinterpret_cast<const uint16_t *>(d + L.lenB), nB, 1, kSlot, stB, nullptr, nullptr, 0, s));
+        HIP_TRY(ctx, launch_hold_fold_runs(stB, reinterpret_cast<const uint16_t *>(d + L.lenB), kSlot, reinterpret_cast<const uint32_t *>(d + L.runB), nrB, ctx->d_hold, s));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fresh, ctx->d_stats, (size_t)staged * sizeof(igdsp_frame_stats), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hold, ctx->d_hold, nch * sizeof(igdsp_chan_hold), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
-    for (uint32_t c = 0; c < nch; ++c)
-        if (!(fresh[c].flags & IGDSP_FLAG_EMPTY)) ctx->h_stats[c] = fresh[c];
+    // 3. a channel's level = the record of its newest frame; a channel with nothing staged keeps its previous level
+    for (uint32_t c = 0; c < nch; ++c) {
+        const uint32_t nw = ctx->newest[c];
+        if (nw == kNone) continue;
+        ctx->h_stats[c] = ctx->h_fresh[(nw & kB) ? nA + (nw & ~kB) : nw];
+    }
     return IGDSP_OK;
 }
 
@@ -208,7 +290,7 @@ int igdsp_poll(igdsp_ctx *ctx, uint32_t channel, igdsp_level *out)
     out->rms = s.rms;
     out->percent = (int32_t)(float)(((double)s.rms * 100.0) / (double)IGDSP_METER_FULL_SCALE);   // audiometer.cpp:30-31
     out->peak_hold = ctx->h_hold[channel].peak_hold;
-    out->reserved = 0;
+    out->dropped = (uint16_t)std::min<uint32_t>(ctx->frames_dropped[channel], 65535u);
     out->frames = ctx->frames_seen[channel];
     return IGDSP_OK;
 }
@@ -451,6 +533,20 @@ int igdsp_probe_placement(igdsp_ctx *ctx, const void *d_in, size_t bytes, void *
     if (e != hipSuccess) return fail(ctx, IGDSP_EDEVICE, "igdsp_probe_placement", e);
     *ms_per_launch = ms / (float)reps;
     return IGDSP_OK;
+}
+
+// Measurement / test helper (not in include/igdsp.h): what `n_calls` media threads do between two ticks, in one native loop —
+// `frames_per_call` calls of igdsp_on_rtp_frame for each of the calls first_call .. first_call + n_calls - 1, frame f of call k
+// taken from payloads[(f * n_calls + k) % n_payloads][payloadlen].  Returns the number of calls that did not return IGDSP_OK.
+int igdsp_internal_stage_many(igdsp_ctx *ctx, int32_t first_call, uint32_t n_calls, uint32_t frames_per_call, uint8_t pt,
+                              const uint8_t *payloads, uint32_t n_payloads, uint32_t payloadlen)
+{
+    if (!ctx || !payloads || n_payloads == 0) return IGDSP_EINVAL;
+    int bad = 0;
+    for (uint32_t f = 0; f < frames_per_call; ++f)
+        for (uint32_t k = 0; k < n_calls; ++k)
+            if (igdsp_on_rtp_frame(ctx, first_call + (int32_t)k, pt, payloads + (size_t)((f * n_calls + k) % n_payloads) * payloadlen, payloadlen) != IGDSP_OK) ++bad;
+    return bad;
 }
 
 // Test-only (not in include/igdsp.h): the table-driven compressor the fused round-trip kernel uses, on arbitrary PCM.

@@ -11,7 +11,8 @@
 #include <vector>
 
 namespace {
-constexpr uint32_t kSlot = IGDSP_MAX_PAYLOAD;          // staging slot bytes per channel (tp_adapter::payload_buff[256])
+constexpr uint32_t kSlot = IGDSP_MAX_PAYLOAD;          // staging slot bytes (tp_adapter::payload_buff[256])
+constexpr uint32_t kStageDepth = IGDSP_STAGE_DEPTH;    // frames per channel between two flushes (8 x 20 ms)
 constexpr uint32_t kNoChan = 0xFFFFFFFFu;
 constexpr int32_t kDirectCalls = 1 << 16;              // pjsua_call_id values are small non-negative ints
 }  // namespace
@@ -30,26 +31,26 @@ struct igdsp_ctx {
     std::unordered_map<int32_t, uint32_t> far;
     std::mutex far_mu;
 
-    // staging (host pinned): slab[c][256], len[c] (0 = nothing staged), pt[c]
-    uint8_t *h_slab = nullptr;
-    uint16_t *h_len = nullptr;
-    uint8_t *h_pt = nullptr;
+    // staging (host pinned): a ring of kStageDepth frames per channel, ring[c][slot][256] + rlen / rpt per slot; head counts frames
+    // written, tail frames taken by igdsp_flush (head - tail <= kStageDepth).  tp_adapter::payload_buff[256] semantics per slot
+    // (TransportAdapter.h:66): the reference's hook runs on EVERY frame (TransportAdapter.cpp:303), so every frame is kept.
+    uint8_t *h_ring = nullptr;
+    uint16_t *h_rlen = nullptr;
+    uint8_t *h_rpt = nullptr;
+    std::vector<uint32_t> head, tail;
     std::vector<std::atomic_flag> slot_lock;
     std::atomic<uint32_t> hi_water{0};                 // 1 + highest channel ever staged
 
-    // upload mirrors + results
-    uint8_t *h_up = nullptr;        // pinned compacted copy taken under the slot locks
-    uint16_t *h_up_len = nullptr;
-    uint8_t *h_up_pt = nullptr;
-    uint8_t *d_slab = nullptr;
-    uint16_t *d_len = nullptr;
-    uint8_t *d_pt = nullptr;
-    igdsp_frame_stats *d_stats = nullptr;
+    // flush: one pinned upload block + its device mirror (sections at 256-byte aligned offsets, one H2D copy), results
+    uint8_t *h_up = nullptr, *d_up = nullptr;
+    size_t up_bytes = 0;
+    igdsp_frame_stats *d_stats = nullptr;               // one record per staged frame of this flush
+    igdsp_frame_stats *h_fresh = nullptr;               // pinned: this flush's records
     igdsp_frame_stats *h_stats = nullptr;               // pinned: last metered record per channel
-    igdsp_frame_stats *h_fresh = nullptr;               // pinned: this flush's records (EMPTY where nothing was staged)
     igdsp_chan_hold *d_hold = nullptr;
     igdsp_chan_hold *h_hold = nullptr;                  // pinned
-    std::vector<uint32_t> frames_seen;
+    std::vector<uint32_t> frames_seen, frames_dropped;  // per channel: frames metered / frames overwritten before a flush took them
+    std::vector<uint32_t> newest;                       // scratch of igdsp_flush: record index of a channel's newest frame
     std::mutex flush_mu;
 
     // device-wide work counters: a ring so that launches in flight on different streams never share one

@@ -43,6 +43,8 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
                             igdsp_chan_hold *hold, const uint8_t *gate, int variant, hipStream_t s);
 hipError_t launch_hold_update(const igdsp_frame_stats *stats, const uint16_t *len, uint32_t C, uint32_t F, uint32_t n,
                               igdsp_chan_hold *hold, const uint8_t *gate, hipStream_t s);
+hipError_t launch_hold_fold_runs(const igdsp_frame_stats *stats, const uint16_t *len, uint32_t n, const uint32_t *runs, uint32_t n_runs,
+                                 igdsp_chan_hold *hold, hipStream_t s);
 hipError_t launch_hold_reset(igdsp_chan_hold *hold, uint32_t C, const uint8_t *mask, hipStream_t s);
 hipError_t launch_depayload(const LaunchCfg &cfg, const uint8_t *packets, const uint16_t *sizes, const uint8_t *radio,
                             uint32_t C, uint32_t F, uint32_t stride, uint32_t n, uint8_t *payload, uint16_t *len,

@@ -62,6 +62,7 @@ struct Explorer {
     igdsp_ctx *ctx = nullptr;
     hipStream_t s = nullptr;
     size_t chunk = 0;
+    size_t va_align = 0;              // alignment asked of every address reservation
     hipMemAllocationProp prop{};
     hipMemAccessDesc acc{};
     void *cand_va = nullptr;          // scratch address space for probing: slot idx belongs to chunk idx, mapped at most once
@@ -124,7 +125,7 @@ struct Explorer {
     {
         Source S;
         S.n = idx.size();
-        if (hipMemAddressReserve(&S.va, S.n * chunk, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipMemAddressReserve(&S.va, S.n * chunk, va_align, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
         sources.push_back(S);
         Source &T = sources.back();
         for (size_t k = 0; k < idx.size(); ++k) {
@@ -146,14 +147,13 @@ struct Explorer {
     void cleanup()
     {
         for (size_t i = 0; i < chunks.size(); ++i) unmap_scratch(i);
-        for (size_t w = 0; w < sources.size(); ++w) { drop_source(w); if (sources[w].va) (void)hipMemAddressFree(sources[w].va, sources[w].n * chunk); }
+        for (size_t w = 0; w < sources.size(); ++w) drop_source(w);
         sources.clear();
         for (auto &c : chunks) if (!c.used) (void)hipMemRelease(c.h);
         chunks.clear();
         if (ea) (void)hipEventDestroy(ea);
         if (eb) (void)hipEventDestroy(eb);
-        if (cand_va) (void)hipMemAddressFree(cand_va, cand_bytes);
-        ea = eb = nullptr; cand_va = nullptr;
+        ea = eb = nullptr; cand_va = nullptr;     // address ranges are never returned: see igdsp_io_free
         (void)hipGetLastError();
     }
 };
@@ -179,11 +179,14 @@ int igdsp_io_free(igdsp_ctx *ctx, igdsp_io_set *set)
     if (!set) return IGDSP_OK;
     (void)hipSetDevice(set->device);
     (void)hipDeviceSynchronize();
+    // Chunks are un-mapped and released; the ADDRESS RANGES stay reserved for the life of the process.  On this stack (ROCm 7.2,
+    // gfx950) an address that has been un-mapped — even freed and reserved again — and is then mapped onto another chunk keeps
+    // reaching the old one (igdsp_internal_vmm_remap_check; tools/io_place.py prints it), so no address is ever handed back for
+    // re-use.  Address space is the only thing this costs (<= ~0.2 TiB of 128 TiB per igdsp_io_alloc call).
     for (auto &m : set->maps) {
         if (!m.va) continue;
         for (size_t i = 0; i < m.handles.size(); ++i) (void)hipMemUnmap((char *)m.va + i * set->chunk, set->chunk);
         for (auto h : m.handles) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(m.va, m.bytes);
     }
     for (void *p : set->plain) if (p) (void)hipFree(p);
     (void)hipGetLastError();
@@ -193,11 +196,13 @@ int igdsp_io_free(igdsp_ctx *ctx, igdsp_io_set *set)
 
 // Diagnostic (not in include/igdsp.h): does a device address that was un-mapped and then mapped onto ANOTHER chunk reach
 // the new chunk?  Writes 0x11 through address v to chunk X, re-maps v onto chunk Y, writes 0x22 through v, then reads X and Y
-// through fresh addresses.  *x_byte / *y_byte receive the first byte of X / Y (expected 0x11 / 0x22; X == 0x22 means the
-// second write still went to X: a stale translation).  igdsp_io_alloc never re-maps an address, whatever this reports.
-int igdsp_internal_vmm_remap_check(igdsp_ctx *ctx, int *x_byte, int *y_byte)
+// through fresh addresses: bytes[0] / bytes[1] = first byte of X / Y (expected 0x11 / 0x22; X == 0x22 means the second write
+// still went to X: a stale translation).  mode 0: hipMemUnmap + hipMemMap on the same reservation; mode 1: the reservation is
+// freed (hipMemAddressFree) and reserved again at the same address in between; bytes[2] = 1 when that second reservation did
+// come back at the same address.  igdsp_io_alloc maps every address at most once, whatever this reports.
+int igdsp_internal_vmm_remap_check(igdsp_ctx *ctx, int mode, int *bytes)
 {
-    if (!ctx || !x_byte || !y_byte) return IGDSP_EINVAL;
+    if (!ctx || !bytes) return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipMemAllocationProp prop{};
     prop.type = hipMemAllocationTypePinned;
@@ -221,6 +226,14 @@ int igdsp_internal_vmm_remap_check(igdsp_ctx *ctx, int *x_byte, int *y_byte)
     HIP_TRY(ctx, hipMemsetAsync(v, 0x11, sz, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemUnmap(v, sz));
+    bytes[2] = 1;
+    if (mode == 1) {
+        void *v0 = v;
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        HIP_TRY(ctx, hipMemAddressFree(v, sz));
+        HIP_TRY(ctx, hipMemAddressReserve(&v, sz, 0, v0, 0));
+        bytes[2] = v == v0 ? 1 : 0;
+    }
     HIP_TRY(ctx, hipMemMap(v, sz, 0, Y, 0));
     HIP_TRY(ctx, hipMemSetAccess(v, sz, &acc, 1));
     HIP_TRY(ctx, hipMemsetAsync(v, 0x22, sz, ctx->stream));
@@ -233,10 +246,10 @@ int igdsp_internal_vmm_remap_check(igdsp_ctx *ctx, int *x_byte, int *y_byte)
     unsigned char bx = 0, by = 0;
     HIP_TRY(ctx, hipMemcpy(&bx, (char *)wx + sz / 2, 1, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(&by, (char *)wy + sz / 2, 1, hipMemcpyDeviceToHost));
-    *x_byte = bx; *y_byte = by;
+    bytes[0] = bx; bytes[1] = by;
     (void)hipMemUnmap(wx, sz); (void)hipMemUnmap(wy, sz);
     (void)hipMemRelease(X); (void)hipMemRelease(Y);
-    (void)hipMemAddressFree(v, sz); (void)hipMemAddressFree(wx, sz); (void)hipMemAddressFree(wy, sz);
+    // the three reservations are deliberately NOT returned: see igdsp_io_free
     return IGDSP_OK;
 }
 
@@ -293,6 +306,8 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
     size_t chunk = (size_t)128 << 20;               // >= the 1/10 of a probe read that a probe launch writes, and small next to the class runs (3-40 GiB)
     chunk = (chunk + gran - 1) / gran * gran;
     X.chunk = set->chunk = chunk;
+    X.va_align = chunk;                             // chunk-aligned addresses: the page tables can then map a chunk with its largest fragments
+    if (const char *e = std::getenv("IGDSP_IO_ALIGN_MIB")) X.va_align = (size_t)std::max(0, std::atoi(e)) << 20;
     R.chunk_bytes = chunk;
 
     // address ranges + chunk counts per buffer
@@ -303,7 +318,7 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
         nch[i] = (bufs[i].bytes + chunk - 1) / chunk;
         auto &m = set->maps[i];
         m.bytes = nch[i] * chunk;
-        if (hipMemAddressReserve(&m.va, m.bytes, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); m.va = nullptr; return finish(fail(ctx, IGDSP_ENOMEM, "igdsp_io_alloc: hipMemAddressReserve")); }
+        if (hipMemAddressReserve(&m.va, m.bytes, X.va_align, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); m.va = nullptr; return finish(fail(ctx, IGDSP_ENOMEM, "igdsp_io_alloc: hipMemAddressReserve")); }
         if (bufs[i].role == IGDSP_IO_INPUT) { in_chunks += nch[i]; in_bytes += bufs[i].bytes; }
         else if (bufs[i].role == IGDSP_IO_RECORD) rec_chunks += nch[i];
         else bulk_chunks += nch[i];
@@ -341,7 +356,7 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
         X.debug = std::getenv("IGDSP_IO_DEBUG") != nullptr;
         size_t stride = 16;                         // sparse survey: one probe per 2 GiB (classes come in runs of 3-40 GiB of consecutive chunks)
         if (const char *e = std::getenv("IGDSP_IO_STRIDE")) stride = std::max(1, std::atoi(e));
-        ok = hipMemAddressReserve(&X.cand_va, X.cand_bytes, 0, nullptr, 0) == hipSuccess;
+        ok = hipMemAddressReserve(&X.cand_va, X.cand_bytes, X.va_align, nullptr, 0) == hipSuccess;
         ok = ok && hipEventCreate(&X.ea) == hipSuccess && hipEventCreate(&X.eb) == hipSuccess;
 
         // measured on MI355X: same-class 0.252 ms, other-class 0.219 ms per probe launch (ratio 1.15), spread inside a level < 1 %
@@ -548,6 +563,23 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
             }
         R.placed = (ok && all) ? 1u : 0u;
         R.bulk_spread = (ok && all && spread && bulk_chunks > 0) ? 1u : 0u;
+        if (X.debug && ok) {                        // the finished set against the levels of the search: first INPUT -> every output buffer
+            std::fprintf(stderr, "[igdsp_io] pools: A %zu B %zu C %zu chunks; A:", poolA.size(), poolB.size(), poolC.size());
+            for (size_t k = 0; k < poolA.size() && k < 12; ++k) std::fprintf(stderr, " %zu", poolA[k]);
+            std::fprintf(stderr, "  B:");
+            for (size_t k = 0; k < poolB.size() && k < 12; ++k) std::fprintf(stderr, " %zu(%.4f)", poolB[k], X.chunks[poolB[k]].tA);
+            std::fprintf(stderr, "\n");
+            int in0 = -1;
+            for (uint32_t i = 0; i < n_bufs; ++i) if (bufs[i].role == IGDSP_IO_INPUT && (in0 < 0 || nch[i] > nch[in0])) in0 = (int)i;
+            for (uint32_t i = 0; i < n_bufs && in0 >= 0 && nch[in0] >= kSrcChunks; ++i) {
+                if (bufs[i].role == IGDSP_IO_INPUT) continue;
+                for (size_t k = 0; k < nch[i] && k < 3; ++k) {
+                    float t = 0.f;
+                    if (X.time_pair(set->maps[in0].va, (char *)set->maps[i].va + k * chunk, &t))
+                        std::fprintf(stderr, "[igdsp_io] final check: input -> buffer %u chunk %zu: %.4f ms\n", i, k, t);
+                }
+            }
+        }
     }
     X.cleanup();                                    // exploration leftovers go back before anything else is allocated
     for (uint32_t role = 0; role < 3 && ok; ++role)
@@ -555,6 +587,21 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
             if (bufs[i].role == role && set->maps[i].handles.size() < nch[i]) ok = map_fresh(i);
     if (!ok) { (void)hipGetLastError(); return finish(fail(ctx, IGDSP_ENOMEM, "igdsp_io_alloc: mapping chunks")); }
     for (uint32_t i = 0; i < n_bufs; ++i) bufs[i].ptr = set->maps[i].va;
+    if (std::getenv("IGDSP_IO_DEBUG") && want_place && R.placed) {   // the same check once more with every exploration chunk released
+        Explorer Y;
+        Y.ctx = ctx; Y.s = ctx->stream; Y.probe_n = kSrcChunks * (chunk - 4096) / 10240 * 10240;
+        if (hipEventCreate(&Y.ea) == hipSuccess && hipEventCreate(&Y.eb) == hipSuccess) {
+            int in0 = -1;
+            for (uint32_t i = 0; i < n_bufs; ++i) if (bufs[i].role == IGDSP_IO_INPUT && (in0 < 0 || nch[i] > nch[in0])) in0 = (int)i;
+            for (uint32_t i = 0; i < n_bufs && in0 >= 0 && nch[in0] >= kSrcChunks; ++i) {
+                if (bufs[i].role == IGDSP_IO_INPUT) continue;
+                float t = 0.f;
+                for (int rep = 0; rep < 3; ++rep)
+                    if (Y.time_pair(set->maps[in0].va, set->maps[i].va, &t)) std::fprintf(stderr, "[igdsp_io] after release: input -> buffer %u: %.4f ms\n", i, t);
+            }
+        }
+        Y.cleanup();
+    }
     return finish(IGDSP_OK);
 }
 

@@ -1874,6 +1874,31 @@ __global__ __launch_bounds__(256) void k_hold_update(const igdsp_frame_stats *__
     hold[c] = h;
 }
 
+// a6 on the drop-in path: fold the records of one flush into hold[c].  The flush compacts every channel's staged frames
+// into consecutive records ("runs": {channel, first record, count}); one thread per run folds them in arrival order
+// (keeplogAudioLevel per frame, Functions.cpp:2126-2145).
+__global__ __launch_bounds__(256) void k_hold_fold_runs(const igdsp_frame_stats *__restrict__ stats, const uint16_t *__restrict__ len,
+                                                        uint32_t n, const uint32_t *__restrict__ runs, uint32_t n_runs,
+                                                        igdsp_chan_hold *__restrict__ hold)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_runs) return;
+    const uint32_t c = runs[3 * r], first = runs[3 * r + 1], count = runs[3 * r + 2];
+    igdsp_chan_hold h = hold[c];
+    for (uint32_t i = first; i < first + count; ++i) {
+        const igdsp_frame_stats s = stats[i];
+        if (s.flags & IGDSP_FLAG_EMPTY) continue;
+        h.sumsq_acc += s.sumsq; h.count += 1u; h.level_sum += s.byte_mean;
+        h.samples += len ? min((uint32_t)len[i], n) : n;
+        h.peak_hold = (uint16_t)max((uint32_t)h.peak_hold, (uint32_t)s.peak);
+        h.level_max = (uint8_t)max((uint32_t)h.level_max, (uint32_t)s.byte_mean);
+        h.level_min = (uint8_t)min((uint32_t)h.level_min, (uint32_t)s.byte_mean);
+        h.n_silent += (s.flags & IGDSP_FLAG_SILENT) ? 1u : 0u;
+        h.n_clipped += (s.flags & IGDSP_FLAG_CLIPPED) ? 1u : 0u;
+    }
+    hold[c] = h;
+}
+
 __global__ __launch_bounds__(256) void k_hold_reset(igdsp_chan_hold *__restrict__ hold, uint32_t C,
                                                     const uint8_t *__restrict__ mask)
 {
@@ -2462,6 +2487,14 @@ hipError_t launch_hold_update(const igdsp_frame_stats *stats, const uint16_t *le
 {
     if (C == 0 || F == 0) return hipSuccess;
     hipLaunchKernelGGL(k_hold_update, dim3((C + 255) / 256), dim3(256), 0, s, stats, len, C, F, n, hold, gate);
+    return hipGetLastError();
+}
+
+hipError_t launch_hold_fold_runs(const igdsp_frame_stats *stats, const uint16_t *len, uint32_t n, const uint32_t *runs, uint32_t n_runs,
+                                 igdsp_chan_hold *hold, hipStream_t s)
+{
+    if (n_runs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_hold_fold_runs, dim3((n_runs + 255) / 256), dim3(256), 0, s, stats, len, n, runs, n_runs, hold);
     return hipGetLastError();
 }
 

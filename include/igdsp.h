@@ -37,7 +37,7 @@ extern "C" {
 #define IGDSP_ENODEV    (-19)  /* no usable gfx950 device / HIP runtime error            */
 #define IGDSP_ENOENT     (-2)  /* call_id not mapped to a channel (a4 routing miss)      */
 #define IGDSP_ERANGE    (-34)  /* channel / frame index out of the context's capacity    */
-#define IGDSP_EBUSY     (-16)  /* staging slot already holds an unflushed frame          */
+#define IGDSP_EBUSY     (-16)  /* staging ring of the channel was full: the OLDEST staged frame was overwritten */
 #define IGDSP_EDEVICE   (-5)   /* kernel launch / runtime failure (see igdsp_last_error) */
 
 /* ---- codec ids: RTP payload types, as gated at TransportAdapter.cpp:252 ---
@@ -52,6 +52,7 @@ extern "C" {
 #define IGDSP_PTIME_MS              20
 #define IGDSP_SAMPLES_PER_FRAME    160
 #define IGDSP_MAX_PAYLOAD          256   /* tp_adapter::payload_buff[256], TransportAdapter.h:66 */
+#define IGDSP_STAGE_DEPTH            8   /* frames a channel can stage between two igdsp_flush calls (160 ms of audio) */
 #define IGDSP_METER_FULL_SCALE   30000   /* audiometer.cpp:30-31 */
 
 /* ---- G.711 encoder variant -------------------------------------------------
@@ -138,8 +139,8 @@ typedef struct igdsp_level {
     float    rms;
     int32_t  percent;     /* int(float(rms*100.0/30000.0)), AudioMeter::onValueChanged */
     uint16_t peak_hold;
-    uint16_t reserved;
-    uint32_t frames;      /* frames flushed for this channel since create            */
+    uint16_t dropped;     /* frames overwritten in the staging ring before a flush took them (saturates at 65535) */
+    uint32_t frames;      /* frames metered for this channel since create            */
 } igdsp_level;
 
 typedef struct igdsp_ctx igdsp_ctx;
@@ -167,19 +168,22 @@ int igdsp_unmap_call(igdsp_ctx *ctx, int32_t call_id);
  * Inputs are exactly what those hooks read from tp_adapter: callID, payload
  * pointer, payload length (roip_ed137.cpp:6549-6552) and the RTP PT
  * (TransportAdapter.cpp:252).  Copies `payload` (borrowed; pjmedia owns pkt) into
- * the channel's staging slot and returns; never blocks on the device.  Safe to
- * call concurrently from several media threads for DIFFERENT channels; for one
- * channel the last frame before a flush wins.  pt == 123 (R2S keep-alive) and
- * unknown PTs are accepted and ignored (returns 0, nothing staged), like the
- * reference which meters only pt != 123.  payloadlen > 256 -> IGDSP_EINVAL
- * (the reference would overflow payload_buff[256] there, TransportAdapter.cpp:286). */
+ * the channel's staging ring (IGDSP_STAGE_DEPTH frames deep: the reference's hook runs on every frame,
+ * TransportAdapter.cpp:303, and so every frame reaches the meter) and returns; never blocks on the device.  Safe to
+ * call concurrently from several media threads for DIFFERENT channels.  If the owner thread has not flushed for more
+ * than IGDSP_STAGE_DEPTH frames the oldest staged frame of the channel is overwritten, counted in igdsp_level.dropped,
+ * and the call returns IGDSP_EBUSY (the new frame IS staged).  pt == 123 (R2S keep-alive) and unknown PTs are accepted
+ * and ignored (returns 0, nothing staged), like the reference which meters only pt != 123.  payloadlen > 256 ->
+ * IGDSP_EINVAL (the reference would overflow payload_buff[256] there, TransportAdapter.cpp:286). */
 int igdsp_on_rtp_frame(igdsp_ctx *ctx, int32_t call_id, uint8_t pt,
                        const uint8_t *payload, uint32_t payloadlen);
 
-/* Upload every slot staged since the previous flush, run the decode+meter kernel
- * over them, fold results into the per-channel hold state, and make them visible
- * to igdsp_poll.  Called by ONE owner thread per context (e.g. a 20 ms timer).
- * `n_frames_out` (optional) receives the number of staged frames processed. */
+/* Take every frame staged since the previous flush (all of them, oldest first per channel), upload them compacted in
+ * one copy, meter them — whole 160-byte frames through the tuned chunk kernel once 64 or more are staged, everything else
+ * through the general kernel — fold EVERY frame into the per-channel hold state (keeplogAudioLevel semantics per frame,
+ * Functions.cpp:2126-2145) and make each channel's newest record visible to igdsp_poll.  Called by ONE owner thread per
+ * context (e.g. the reference's 40 ms timer, roip_ed137.cpp:1756).  `n_frames_out` (optional) receives the number of
+ * staged frames processed. */
 int igdsp_flush(igdsp_ctx *ctx, uint32_t *n_frames_out);
 
 /* (iii) results poll for one channel (valid after a flush). */

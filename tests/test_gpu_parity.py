@@ -422,6 +422,67 @@ def test_staging_flush_poll_mirror_of_setIncomingRTP(ctx, orc):
         ctx.unmap_call(cid)
 
 
+@pytest.mark.parametrize("nch", [5, 200])
+def test_staging_ring_meters_every_frame(orc, nch):
+    """20 ms frames against a 40 ms tick (roip_ed137.cpp:1756): 2-3 frames are staged per call between two flushes.  The
+    reference's hook runs on EVERY frame (TransportAdapter.cpp:303), so hold.count / level_sum / sumsq_acc / peak_hold /
+    n_silent must equal the oracle's fold over ALL frames (keeplogAudioLevel per frame, Functions.cpp:2126-2145), the polled
+    level is the NEWEST frame's, lengths other than 160 and a PT change mid-call ride along, and with >= 64 whole frames
+    staged the records come from the tuned chunk kernel (nch = 200)."""
+    c = capi.Context(device=0, max_channels=nch)
+    try:
+        for ch in range(nch):
+            c.map_call(100 + ch, ch)
+        rng = np.random.default_rng(nch)
+        hold = orc.hold_new(nch)
+        total = np.zeros(nch, np.int64)
+        last = {}
+        for tick in range(7):
+            staged = 0
+            for ch in range(nch):
+                k = int(rng.integers(0, 4)) if ch else 3                      # 0..3 frames this tick; channel 0 always 3
+                for j in range(k):
+                    ln = 160 if (ch % 7) else int(rng.choice([24, 164, 160, 1, 255]))   # every 7th channel: odd lengths too
+                    pt = 8 if (ch % 3 == 0 and tick >= 3) else 0              # law change mid-call
+                    pl = orc.gen_uniform(ln, seed=10000 * tick + 10 * ch + j)
+                    if ch == 1 and j == 0:
+                        pl = np.full(ln, 0xFF, np.uint8)                       # digital silence
+                    assert c.on_rtp_frame(100 + ch, pt, pl.tobytes()) == 0
+                    est = orc.decode_meter(pl.reshape(1, 1, -1), [pt])
+                    orc.hold_update(est, ln, hold[ch:ch + 1])
+                    last[ch] = (est, ln)
+                    staged += 1
+                    total[ch] += 1
+            assert c.flush() == staged
+            for ch in range(nch):
+                if ch not in last:
+                    continue
+                lv, (est, ln) = c.poll(ch), last[ch]
+                assert (lv.byte_mean, lv.peak, lv.flags) == (int(est["byte_mean"][0, 0]), int(est["peak"][0, 0]), int(est["flags"][0, 0])), (tick, ch)
+                ref = np.sqrt(float(est["sumsq"][0, 0]) / ln)
+                assert abs(lv.rms - ref) <= 1e-5 * ref + 1e-30
+                assert lv.frames == total[ch] and lv.dropped == 0
+        for ch in range(nch):
+            h = c.get_hold(ch)
+            for f in capi.CHAN_HOLD.names:
+                assert int(h[f]) == int(hold[f][ch]), (f, ch)
+        # overflow: the ring holds IGDSP_STAGE_DEPTH frames; the 9th overwrites the oldest, says so, and is counted
+        before = int(c.get_hold(0)["count"])
+        pls = [orc.gen_uniform(160, seed=777 + j) for j in range(capi.STAGE_DEPTH + 2)]
+        rcs = [c.on_rtp_frame(100, 0, p.tobytes()) for p in pls]
+        assert rcs == [0] * capi.STAGE_DEPTH + [-16, -16]
+        assert c.flush() == capi.STAGE_DEPTH
+        lv = c.poll(0)
+        assert lv.dropped == 2 and int(c.get_hold(0)["count"]) == before + capi.STAGE_DEPTH
+        assert lv.byte_mean == orc.byte_mean(pls[-1])                          # the newest frame survived
+        exp = orc.hold_new(1)
+        for p in pls[2:]:
+            orc.hold_update(orc.decode_meter(p.reshape(1, 1, -1), [0]), 160, exp)
+        c.reset_hold(0)
+    finally:
+        c.close()
+
+
 # ----------------------------------------------------------------------------- full-size properties
 @pytest.fixture(scope="module")
 def big(ctx):
@@ -664,3 +725,74 @@ def test_dev_alloc_far(ctx):
     assert fn(ctx.h, C.byref(ptr), 0, src.data_ptr(), nbytes, 4, 0, None, None) == -22
     assert fn(ctx.h, C.byref(ptr), 1 << 20, None, nbytes, 4, 0, None, None) == -22
     assert fn(ctx.h, C.byref(ptr), 1 << 20, src.data_ptr(), nbytes, 0, 0, None, None) == -22
+
+
+def test_io_alloc_places_buffers_and_they_work(ctx, orc):
+    """igdsp_io_alloc (the placement that round 1 kept in bench.py, now in the product): one call for a config-#5-shaped buffer
+    set at the headline size.  (i) the buffers behave like any device memory: the fused round trip on them equals the run on
+    plain torch buffers byte for byte, and sampled frames equal the oracle; (ii) when the box shows more than one class of
+    device memory, the bare read + record stream from the placed input into the placed record buffer is >= 8 % faster than the
+    same stream writing into the input's OWN class (what consecutive plain allocations normally give); (iii) small sets are
+    served without probing; argument rules."""
+    torch = gu.torch_cuda()
+    C_, F_, n = 65536, 128, 160
+    B = F_ * C_ * n
+    s = torch.cuda.current_stream().cuda_stream
+    ioset, (p_in, p_st, p_out), rep = ctx.io_alloc([(B, capi.IO_INPUT), (F_ * C_ * 16, capi.IO_RECORD), (B, capi.IO_BULK)])
+    try:
+        assert p_in and p_st and p_out and p_in % (2 << 20) == 0 and rep["chunk_bytes"] >= (2 << 20)
+        d_pl, d_st, d_out = capi.as_tensor(p_in, B), capi.as_tensor(p_st, F_ * C_ * 16), capi.as_tensor(p_out, B)
+        ctx.gen_uniform(d_pl, B, stream=s)
+        codec = np.where(np.arange(C_) & 1, 8, 0).astype(np.uint8)
+        d_cd = gu.to_dev(codec)
+        hold_a, hold_b = gu.to_dev(gu.new_hold(C_)), gu.to_dev(gu.new_hold(C_))
+        ctx.roundtrip_peakhold(d_pl, d_cd, C_, F_, n, d_out, d_st, hold_a, stream=s)
+        t_pl = d_pl.clone()
+        t_st, t_out = torch.empty_like(d_st), torch.empty_like(d_out)
+        ctx.roundtrip_peakhold(t_pl, d_cd, C_, F_, n, t_out, t_st, hold_b, stream=s)
+        torch.cuda.synchronize()
+        assert torch.equal(d_out, t_out) and torch.equal(d_st, t_st) and torch.equal(hold_a, hold_b)
+        st = gu.to_host(d_st, capi.FRAME_STATS)
+        rng = np.random.default_rng(3)
+        for fi in np.unique(np.concatenate([[0, C_ * F_ - 1], rng.integers(0, C_ * F_, 400)])):
+            e = orc.decode_meter(orc.gen_uniform(n, first_byte=int(fi) * n).reshape(1, 1, n), [int(codec[int(fi) % C_])])[0, 0]
+            assert (int(st[fi]["sumsq"]), int(st[fi]["peak"]), int(st[fi]["byte_mean"])) == (int(e["sumsq"]), int(e["peak"]), int(e["byte_mean"]))
+        if rep["classes_found"] >= 2:
+            assert rep["placed"] == 1 and rep["probe_ms_other"] <= 0.92 * rep["probe_ms_same"]
+            # The library's two levels come from its own probe stream on freshly created (zero) memory; with real data the same
+            # stream runs ~4 % slower at either level, so the placed pair is compared with a NAIVE pair on the same data: plain
+            # consecutive allocations through the ABI, as a host following the header literally would make them.
+            n_in, n_st = ctx.dev_alloc(B), ctx.dev_alloc(F_ * C_ * 16)
+            try:
+                ctx.gen_uniform(n_in, B, stream=s)
+                for _ in range(12):                                                 # clocks, and the driver's clearing of the memory freed above
+                    ctx.probe_placement(d_pl, B, out=d_st, reps=10, stream=s)
+                t_placed = min(ctx.probe_placement(d_pl, B, out=d_st, reps=10, stream=s) for _ in range(3))
+                t_naive = min(ctx.probe_placement(n_in, B, out=n_st, reps=10, stream=s) for _ in range(3))
+            finally:
+                ctx.dev_free(n_in)
+                ctx.dev_free(n_st)
+            print(f"bare stream, whole batch -> records: placed {t_placed:.4f} ms, naive {t_naive:.4f} ms, report {rep}")
+            assert t_placed <= 1.03 * t_naive, (t_placed, t_naive)                  # never worse
+            if t_naive > 1.05 * t_placed:                                           # the naive pair shares one class (the usual case):
+                assert t_placed <= 0.94 * t_naive, (t_placed, t_naive, rep)         # measured 7.5-9 % (0.234 vs 0.255 ms); 13-20 % for bulk outputs
+    finally:
+        ioset.close()
+    # small inputs: nothing to place, nothing probed
+    ioset, ptrs, rep = ctx.io_alloc([(1 << 20, capi.IO_INPUT), (4096, capi.IO_RECORD)])
+    assert all(ptrs) and rep["placed"] == 0 and rep["probes"] == 0
+    t = capi.as_tensor(ptrs[1], 4096)
+    t.fill_(7)
+    torch.cuda.synchronize()
+    assert int(t.sum().item()) == 7 * 4096
+    ioset.close()
+    # argument rules
+    arr = (capi.IoBuf * 1)()
+    arr[0].bytes, arr[0].role = 0, capi.IO_INPUT
+    import ctypes as C
+    st_, r_ = C.c_void_p(), capi.IoReport()
+    assert ctx.L.igdsp_io_alloc(ctx.h, arr, 1, 0, C.byref(st_), C.byref(r_)) == -22
+    arr[0].bytes, arr[0].role = 4096, 9
+    assert ctx.L.igdsp_io_alloc(ctx.h, arr, 1, 0, C.byref(st_), C.byref(r_)) == -22
+    assert ctx.L.igdsp_io_alloc(ctx.h, arr, 0, 0, C.byref(st_), C.byref(r_)) == -22
+    assert ctx.L.igdsp_io_free(ctx.h, None) == 0

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Latency of the drop-in per-frame path: stage one 20 ms frame per call with igdsp_on_rtp_frame, then igdsp_flush
-(the 40 ms owner-thread tick of the reference).  Prints host-side wall time per flush for 4 / 32 / 64 / 1024 calls."""
+"""Latency of the drop-in per-frame path at the reference's cadence: every call stages TWO 20 ms frames with
+igdsp_on_rtp_frame between two ticks, then the owner thread's igdsp_flush runs (the 40 ms timer, roip_ed137.cpp:1756).
+Prints host-side wall time per flush and per staged frame for 4 / 32 / 1 024 / 65 536 calls (staging in one native loop,
+igdsp_internal_stage_many, so Python's call overhead is not in the figure)."""
+import ctypes as C
 import os
 import sys
 import time
@@ -14,27 +17,33 @@ from igate4xsoftphonedsp_amd import capi  # noqa: E402
 
 
 def main():
-    for nch in (4, 32, 64, 1024):
+    fpc = 2
+    for nch in (4, 32, 1024, 65536):
         ctx = capi.Context(device=0, max_channels=nch)
         for c in range(nch):
-            ctx.map_call(1000 + c, c)
+            ctx.map_call(c, c)
         rng = np.random.default_rng(nch)
-        frames = [rng.integers(0, 256, 160, dtype=np.uint8).tobytes() for _ in range(nch)]
+        pool = rng.integers(0, 256, (4096, 160), dtype=np.uint8)
+        buf = pool.ctypes.data_as(C.c_void_p)
+        fn = ctx.L.igdsp_internal_stage_many
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint8, C.c_void_p, C.c_uint32, C.c_uint32]
         ts, ts_stage = [], []
-        for it in range(220):
+        iters = 220 if nch <= 1024 else 40
+        for it in range(iters):
             t0 = time.perf_counter()
-            for c in range(nch):
-                ctx.on_rtp_frame(1000 + c, 0, frames[c])
+            assert fn(ctx.h, 0, nch, fpc, 0, buf, 4096, 160) == 0
             t1 = time.perf_counter()
             n = ctx.flush()
             t2 = time.perf_counter()
-            assert n == nch
-            if it >= 20:
+            assert n == nch * fpc
+            if it >= 10:
                 ts.append(t2 - t1)
-                ts_stage.append((t1 - t0) / nch)
-        lv = ctx.poll(0)
-        print(f"{nch:5d} calls: flush median {np.median(ts) * 1e6:7.1f} us  p99 {np.percentile(ts, 99) * 1e6:7.1f} us   "
-              f"(staging via ctypes {np.median(ts_stage) * 1e6:.2f} us per frame)  ch0 rms {lv.rms:.1f} peak {lv.peak}")
+                ts_stage.append((t1 - t0) / (nch * fpc))
+        lv, h = ctx.poll(0), ctx.get_hold(0)
+        assert lv.frames == iters * fpc == int(h["count"]) and lv.dropped == 0
+        print(f"{nch:6d} calls x {fpc} frames: flush median {np.median(ts) * 1e6:9.1f} us  p99 {np.percentile(ts, 99) * 1e6:9.1f} us   "
+              f"staging {np.median(ts_stage) * 1e9:6.0f} ns per frame   ch0 rms {lv.rms:.1f} peak {lv.peak} frames {lv.frames}", flush=True)
         ctx.close()
 
 

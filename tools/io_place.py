@@ -26,9 +26,10 @@ def run(mode, pl, st, bulk, cd, hold):
     if mode == "encode": return lambda: ctx.encode(pl, cd, C_, F_, n, bulk, stream=hs)
 
 import ctypes as CT
-xb, yb = CT.c_int(-1), CT.c_int(-1)
-rc = ctx.L.igdsp_internal_vmm_remap_check(ctx.h, CT.byref(xb), CT.byref(yb))
-print("vmm_remap_check rc", rc, "X byte", hex(xb.value), "(expect 0x11)  Y byte", hex(yb.value), "(expect 0x22)", flush=True)
+for mode in (0, 1):
+    b3 = (CT.c_int * 3)(-1, -1, -1)
+    rc = ctx.L.igdsp_internal_vmm_remap_check(ctx.h, mode, b3)
+    print("vmm_remap_check mode", mode, "rc", rc, "X byte", hex(b3[0]), "(expect 0x11)  Y byte", hex(b3[1]), "(expect 0x22)  same address", b3[2], flush=True)
 res = {}
 for mode in modes:
     in_b = B * (2 if mode == "encode" else 1)
@@ -47,11 +48,23 @@ for mode in modes:
     bufs = [(in_b, capi.IO_INPUT), (F_ * C_ * 16, capi.IO_RECORD)] + ([(bulk_b, capi.IO_BULK)] if bulk_b else [])
     st_, ptrs, rep = ctx.io_alloc(bufs)
     rep["wall_s"] = round(time.time() - t0, 2)
+    pz = min(ctx.probe_placement(ptrs[0], B, out=ptrs[1], reps=10, stream=hs) for _ in range(3))
+    print("probe placed, input as allocated (zeros): %.4f ms" % pz, flush=True)
     ctx.gen_uniform(ptrs[0], in_b, stream=hs)
+    pz = min(ctx.probe_placement(ptrs[0], B, out=ptrs[1], reps=10, stream=hs) for _ in range(3))
+    print("probe placed, input random: %.4f ms" % pz, flush=True)
     g = run(mode, ptrs[0], ptrs[1], ptrs[2] if bulk_b else None, cd, hold)
     for _ in range(3): gpu_ms(g, 50)
     t_placed = min(gpu_ms(g, 50) for _ in range(3))
     t_naive2 = min(gpu_ms(f, 50) for _ in range(3))
+    for reps in (2, 4, 10, 50):
+        a = min(ctx.probe_placement(ptrs[0], B, out=ptrs[1], reps=reps, stream=hs) for _ in range(3))
+        b = min(ctx.probe_placement(ptrs[0], B, out=ptrs[1], reps=reps, stream=None) for _ in range(3))
+        c = min(gpu_ms(g, reps) for _ in range(3))
+        print("reps %d: probe on torch stream %.4f  on null stream %.4f   kernel %.4f ms" % (reps, a, b, c), flush=True)
+    pr_placed = min(ctx.probe_placement(ptrs[0], B, out=ptrs[1], reps=10, stream=hs) for _ in range(3))
+    pr_naive = min(ctx.probe_placement(p_in, B, out=p_st, reps=10, stream=hs) for _ in range(3))
+    print("probe (whole batch -> records): placed %.4f ms  naive %.4f ms   va in %#x st %#x" % (pr_placed, pr_naive, ptrs[0], ptrs[1]), flush=True)
     # read-only stream over both inputs (is VMM-mapped memory as fast to read as hipMalloc memory?)
     sink = torch.zeros((1,), dtype=torch.int64, device="cuda")
     r_naive = gpu_ms(lambda: ctx.stream_read(p_in, in_b, sink, stream=hs), 20)
