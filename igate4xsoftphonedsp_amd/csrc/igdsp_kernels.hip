@@ -762,6 +762,191 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_meter_fat(
 }
 
 // ============================================================================
+// Every other frame size — k_meter_image: decode + meter for any n with n % 4 == 0 (24, 80, 164, 240 ... the reference's
+// hook anticipates 164 and 24, roip_ed137.cpp:6561-6562), optional per-frame lengths, whole super-chunks AND the tail.
+//
+// A 16-byte piece of a [F][C][n] stream straddles frames when n % 16 != 0, so the piece / strip bookkeeping of
+// k_meter_chunk64 does not carry over.  Instead the wave copies its super-chunk (64 frames = 64 n contiguous bytes, fetched
+// with the same wave-wide 16 B/lane nontemporal loads) into an LDS image and then lane l meters FRAME l on its own: n / 4
+// steps of {one ds_read_b32 of its frame, four LUT reads, accumulate}.  All 64 lanes stay busy for any n, no cross-lane
+// fold exists, the probe bytes and the per-frame length are the lane's own, and the 64 records leave as one 1 KiB store.
+// The pieces of the NEXT super-chunk are already in flight (in registers) while the current image is metered.
+// Lane l starts at dword l * n / 4 of the image: conflict-free when n / 4 is odd (164), 2- to 8-way for the image reads
+// (one LDS read in five) when it is even; the LUT reads are conflict-free as everywhere (replica = lane & 31).
+// LDS: 64 KiB LUT + 64 n bytes of image per wave, so the block runs min(12, 94 KiB / 64 n) waves (9 at n = 164).
+// Algorithmic bytes per sample: (n + 1 + 16) / n.
+// ============================================================================
+constexpr int kImgMaxPieces = IGDSP_MAX_PAYLOAD * kSuperFrames / 16 / 64;      // 16 wave-wide loads cover 64 frames of 256 bytes
+
+constexpr uint32_t kImgMaxWaves = 12;          // 768 threads: up to 170 VGPRs, room for the sixteen piece registers of the next item
+
+template <bool AGG, bool RAGGED>
+__global__ __launch_bounds__(kImgMaxWaves * 64) void k_meter_image(
+    const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, const uint16_t *__restrict__ len, uint32_t C,
+    uint32_t first_frame, uint32_t n_frames, uint32_t n, igdsp_frame_stats *__restrict__ stats, igdsp_aggregate *agg, uint32_t rank)
+{
+    // frames [first_frame, n_frames) of the batch in items of 64; all pointers are the batch bases; payload + first_frame * n
+    // is 16-byte aligned (launcher)
+    __shared__ uint2 lut[kLutEntries];                            // static, at LDS offset 0: LUT addresses need no base add
+    extern __shared__ __attribute__((aligned(16))) uint8_t img_smem[];   // the waves' images (sized at launch)
+    const uint32_t n_waves = blockDim.x >> 6;
+    fill_lut(lut);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t img_bytes = (uint32_t)kSuperFrames * n;
+    uint32_t *img = reinterpret_cast<uint32_t *>(img_smem + (size_t)wave * img_bytes);
+    const uint32_t off = (lane & 31u) * 8u;
+    const uint32_t D = n >> 2;                                   // dwords per frame
+    const uint32_t np = (img_bytes / 16u + 63u) >> 6;            // wave-wide loads per item (<= 16)
+    const uint32_t n_items = (n_frames - first_frame + (uint32_t)kSuperFrames - 1u) / (uint32_t)kSuperFrames;
+    const uint64_t total_bytes = (uint64_t)n_frames * n;
+    const uint8_t *base0 = payload + (uint64_t)first_frame * n;
+
+    uint64_t a_sumsq = 0;
+    uint32_t a_samp = 0, a_bm = 0, a_peak = 0;
+    uint32_t u_frames = 0, u_sil = 0, u_clip = 0;
+
+    uint4 d[kImgMaxPieces];
+    // bytes of item `it` that exist in the batch (the last item may be short)
+    auto avail_of = [&](uint32_t it) {
+        const uint64_t b = (uint64_t)first_frame * n + (uint64_t)it * img_bytes;
+        return (uint32_t)min((uint64_t)img_bytes, total_bytes - b);
+    };
+    // Every load is unconditional (a piece that does not exist in the batch re-reads the batch's first 16 bytes and is never
+    // stored): no load result is merged with another value, so the compiler keeps counted vmcnt waits and the pieces of the next
+    // item really are in flight while the current image is metered.
+    auto fetch = [&](uint32_t it) {
+        const uint8_t *src = base0 + (uint64_t)it * img_bytes;
+        const uint32_t avail = avail_of(it);
+#pragma unroll
+        for (int j = 0; j < kImgMaxPieces; ++j)
+            if ((uint32_t)j < np) {                              // wave-uniform
+                const uint32_t o = ((uint32_t)j * 64u + lane) * 16u;
+                const uint8_t *a = (o + 16u <= avail) ? src + o : payload;
+                d[j] = ld_stream(reinterpret_cast<const uint4 *>(a));
+            }
+    };
+    const uint32_t stride_items = gridDim.x * n_waves;
+    uint32_t item = blockIdx.x * n_waves + wave;
+    if (item < n_items) fetch(item);
+    for (; item < n_items; item += stride_items) {
+        // registers -> image (the previous item's readers are this same wave: program order + fence)
+        const uint32_t avail = avail_of(item);
+#pragma unroll
+        for (int j = 0; j < kImgMaxPieces; ++j)
+            if ((uint32_t)j < np) {
+                const uint32_t o = ((uint32_t)j * 64u + lane) * 16u;
+                if (o + 16u <= avail) *reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(img) + o) = d[j];
+            }
+        if ((avail & 15u) != 0u) {                               // wave-uniform, once per launch at most: the batch ends inside a piece
+            const uint32_t o = (avail & ~15u) + 4u * lane;       // its 1..3 dwords, one lane each
+            if (o < avail) img[o >> 2] = *reinterpret_cast<const uint32_t *>(base0 + (uint64_t)item * img_bytes + o);
+        }
+        const uint32_t nxt = item + stride_items;
+        if (nxt < n_items) fetch(nxt);                           // in flight while this image is metered
+        wave_lds_fence();
+        const uint32_t fi = first_frame + item * (uint32_t)kSuperFrames + lane;
+        const bool live = fi < n_frames;
+        const uint32_t fic = live ? fi : n_frames - 1u;
+        const bool alaw = codec[fic % C] == IGDSP_PT_PCMA;
+        uint32_t l = live ? (len ? min((uint32_t)len[fic], n) : n) : 0u;
+        const uint32_t lm = alaw ? 0x80808080u : 0u;
+        const uint32_t *row = img + lane * D;
+        uint64_t s = 0;
+        uint32_t peak = 0, bsum = 0;
+        const uint32_t steps = (l + 3u) >> 2;                    // dwords this lane meters (its own loop bound)
+        uint32_t i_first = 0;
+        if (!RAGGED) {
+            // dense frames: every lane walks the same D dwords, in units of two dwords = 8 samples.  Two-deep software pipeline as
+            // in process_half: the eight LUT reads of unit u + 1 and the two image reads of unit u + 2 are in flight while unit
+            // u is folded (reads past the frame's end are clamped to its last dword and never folded).
+            const uint32_t units = D >> 1, last = D - 1u;
+            uint2 ea[8], eb[8];
+            uint32_t wa0, wa1, wb0, wb1;                          // image dwords of the unit in ea / eb
+            auto issue = [&](uint32_t x0, uint32_t x1, uint2 (&e)[8]) {
+                const uint32_t t0 = (x0 & 0x7F7F7F7Fu) | lm, t1 = (x1 & 0x7F7F7F7Fu) | lm;
+                e[0] = lut_at(lut, t0, off, 0x0C0C0400u); e[1] = lut_at(lut, t0, off, 0x0C0C0500u); e[2] = lut_at(lut, t0, off, 0x0C0C0600u); e[3] = lut_at(lut, t0, off, 0x0C0C0700u);
+                e[4] = lut_at(lut, t1, off, 0x0C0C0400u); e[5] = lut_at(lut, t1, off, 0x0C0C0500u); e[6] = lut_at(lut, t1, off, 0x0C0C0600u); e[7] = lut_at(lut, t1, off, 0x0C0C0700u);
+            };
+            uint32_t part = 0;
+            auto fold = [&](uint32_t x0, uint32_t x1, const uint2 (&e)[8]) {
+                bsum = __builtin_amdgcn_sad_u8(x0, 0u, bsum); bsum = __builtin_amdgcn_sad_u8(x1, 0u, bsum);
+                part = part + e[0].x + e[1].x; part = part + e[2].x + e[3].x; part = part + e[4].x + e[5].x; part = part + e[6].x + e[7].x;
+                peak = max(max(peak, e[0].y), e[1].y); peak = max(max(peak, e[2].y), e[3].y);
+                peak = max(max(peak, e[4].y), e[5].y); peak = max(max(peak, e[6].y), e[7].y);
+            };
+            // image dwords travel two units ahead of the LUT reads that use them and are ISSUED before those: LDS returns in
+            // order, so a wait for a dword pair must never sit behind the eight LUT reads issued after it
+            const uint32_t lastu = units ? units - 1u : 0u;
+            auto rd = [&](uint32_t uu, uint32_t &x0, uint32_t &x1) { const uint32_t *q = row + 2u * min(uu, lastu); x0 = q[0]; x1 = q[min(1u, last)]; };
+            uint32_t wc0, wc1, wd0, wd1;
+            rd(0u, wa0, wa1); rd(1u, wb0, wb1); rd(2u, wc0, wc1);
+            issue(wa0, wa1, ea);
+            uint32_t u = 0;
+            for (; u + 2u <= units; u += 2u) {                     // unit u sits in ea (dwords wa), unit u + 1 is issued into eb (dwords wb)
+                rd(u + 3u, wd0, wd1);
+                issue(wb0, wb1, eb);
+                __builtin_amdgcn_sched_barrier(0);
+                fold(wa0, wa1, ea);
+                rd(u + 4u, wa0, wa1);
+                issue(wc0, wc1, ea);                              // unit u + 2
+                __builtin_amdgcn_sched_barrier(0);
+                fold(wb0, wb1, eb);
+                { const uint32_t t0 = wa0, t1 = wa1; wa0 = wc0; wa1 = wc1; wb0 = wd0; wb1 = wd1; wc0 = t0; wc1 = t1; }
+                if ((u & 2u) != 0u) { s += part; part = 0; }      // every 32 samples: 32 x 2^26 still fits 32 bits
+            }
+            if (u < units) { fold(wa0, wa1, ea); u += 1u; }       // an odd unit count leaves one issued unit in ea
+            s += part;
+            i_first = u << 1;                                      // the D % 2 dword left over takes the general loop below
+        }
+        for (uint32_t i0 = i_first; i0 < steps; i0 += 4u) {      // 16 samples per pass: (|x|/4)^2 < 2^26 each, the pass sum fits 32 bits
+            uint32_t part = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t i = i0 + k;
+                if (i < steps) {
+                    uint32_t w = row[i];
+                    const uint32_t nv = min(l - 4u * i, 4u);       // bytes of this dword inside the frame's length
+                    const uint32_t t = (w & 0x7F7F7F7Fu) | lm;
+                    const uint2 e0 = lut_at(lut, t, off, 0x0C0C0400u), e1 = lut_at(lut, t, off, 0x0C0C0500u);
+                    const uint2 e2 = lut_at(lut, t, off, 0x0C0C0600u), e3 = lut_at(lut, t, off, 0x0C0C0700u);
+                    if (nv == 4u) {
+                        part += e0.x + e1.x + e2.x + e3.x;
+                        peak = max(max(peak, e0.y), max(e1.y, max(e2.y, e3.y)));
+                    } else {                                       // last dword of a ragged frame
+                        part += e0.x + (nv > 1u ? e1.x : 0u) + (nv > 2u ? e2.x : 0u);
+                        peak = max(max(peak, e0.y), max(nv > 1u ? e1.y : 0u, nv > 2u ? e2.y : 0u));
+                        w &= (1u << (8u * nv)) - 1u;
+                    }
+                    bsum = __builtin_amdgcn_sad_u8(w, 0u, bsum);
+                }
+            }
+            s += part;
+        }
+        // the reference's silence probe: payload bytes 28 / 38 / 48 of the lane's own frame
+        bool probe = false;
+        if (l > 48u) probe = ((row[7] & 0xFFu) == 0xD5u) && (((row[9] >> 16) & 0xFFu) == 0xD5u) && ((row[12] & 0xFFu) == 0xD5u);
+        uint32_t bm = 0, fl = 0;
+        uint4 rec = make_uint4(0u, 0u, 0u, (uint32_t)IGDSP_FLAG_EMPTY << 24);
+        if (l != 0u) rec = pack_stats(s << 4, peak, bsum, l, alaw, probe, bm, fl);
+        if (live) st_stream(reinterpret_cast<uint4 *>(stats + fi), rec);
+        if (AGG) {
+            const bool met = l != 0u;
+            if (met) { a_sumsq += s << 4; a_samp += l; a_bm += bm; a_peak = max(a_peak, peak); }
+            u_frames += (uint32_t)__builtin_popcountll(__ballot(met));
+            u_sil += (uint32_t)__builtin_popcountll(__ballot(met && (fl & IGDSP_FLAG_SILENT) != 0u));
+            u_clip += (uint32_t)__builtin_popcountll(__ballot(met && (fl & IGDSP_FLAG_CLIPPED) != 0u));
+        }
+        wave_lds_fence();
+    }
+    if (AGG && agg != nullptr) {
+        __shared__ uint2 agg_slots[kWavesPerBlock * 4];
+        const bool l0 = lane == 0u;
+        agg_commit_block(agg, rank, agg_slots, n_waves, a_sumsq, (uint64_t)a_samp, l0 ? u_frames : 0u, l0 ? u_sil : 0u, l0 ? u_clip : 0u, a_bm, a_peak);
+    }
+}
+
+// ============================================================================
 // Fused packet path — k_meter_rtp64: depayload + decode + meter in one pass over 192-byte packet slots
 // (include/igdsp.h, igdsp_decode_meter_rtp).  Same machinery as k_meter_chunk64 with 12 pieces per
 // slot instead of 10: pieces 0 and 1 of a slot are {size, pad, RTP bytes 0-3} and {RTP bytes 4-19}; they
@@ -1684,7 +1869,7 @@ template <int VARIANT>
 __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_lut64(
     const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F,
     uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats, igdsp_chan_hold *__restrict__ hold,
-    const uint8_t *__restrict__ gate, uint32_t n_seg, uint32_t n_groups)
+    const uint8_t *__restrict__ gate, uint32_t n_seg, uint32_t n_groups, uint32_t order)
 {
     // Work item = (group of 64 consecutive channels, segment of the F frames), as in k_roundtrip_chunk64: n_seg == 1 ->
     // the wave owns hold[c] outright; n_seg > 1 -> windows merge by device-scope integer atomics (exact, order-free).
@@ -1706,7 +1891,10 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_lut64(
     const uint32_t total_waves = gridDim.x * kRtlWaves;
     const uint32_t fstride16 = C * (uint32_t)kPiecesPerFrame;       // uint4 units between frames of one channel group
 
-    for (uint32_t item = wave * gridDim.x + blockIdx.x; item < n_groups * n_seg; item += total_waves) {
+    // order 0: the waves of a block take items a grid apart (neighbouring BLOCKS touch neighbouring groups); order 1: the
+    // waves of a block take consecutive items (one block touches kRtlWaves neighbouring groups = 120 KiB per frame)
+    const uint32_t first = order ? blockIdx.x * (uint32_t)kRtlWaves + wave : wave * gridDim.x + blockIdx.x;
+    for (uint32_t item = first; item < n_groups * n_seg; item += total_waves) {
         const uint32_t seg = item / n_groups, cg = item - seg * n_groups;
         const uint32_t f_lo = (uint32_t)(((uint64_t)F * seg) / n_seg), f_hi = (uint32_t)(((uint64_t)F * (seg + 1u)) / n_seg);
         if (f_lo >= f_hi) continue;
@@ -2363,8 +2551,39 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
         if (e != hipSuccess) return e;
     }
     if (done < n_frames) {
-        const uint32_t grid = blocks_for((n_frames - done + 7) / 8, 4, (uint32_t)cfg.compute_units * 8u);
-        hipLaunchKernelGGL(k_meter_wave_per_frame, dim3(grid), dim3(256), 0, s, payload, codec, len, C, done, n_frames, n, stats, pcm, agg, rank);
+        // what the tuned n == 160 kernel does not take: other frame sizes, ragged lengths, the < 64-frame tail.  Meter-only
+        // work with n % 4 == 0 goes through the LDS-image kernel (every lane meters one frame); PCM output, n % 4 != 0 and
+        // unaligned buffers through the literal wave-per-frame kernel.
+        const bool image_ok = variant != 1 && pcm == nullptr && (n & 3u) == 0u && ((reinterpret_cast<uintptr_t>(stats) & 15u) == 0u) &&
+                              (((reinterpret_cast<uintptr_t>(payload) + (uint64_t)done * n) & 15u) == 0u) && n_frames - done >= 16u;
+        if (image_ok) {
+            const uint32_t img = (uint32_t)kSuperFrames * n;
+            const uint32_t lut_bytes = (uint32_t)kLutEntries * 8u;
+            const uint32_t waves = std::max(1u, std::min(kImgMaxWaves, (160u * 1024u - lut_bytes - 2048u) / img));
+            const uint32_t items = (n_frames - done + (uint32_t)kSuperFrames - 1u) / (uint32_t)kSuperFrames;
+            const uint32_t grid = blocks_for(items, waves, (uint32_t)cfg.compute_units);
+            const size_t smem = (size_t)waves * img;              // dynamic part: the images (the LUT is static)
+            static bool attr_set = false;      // more than 64 KiB of dynamic LDS needs the attribute once per kernel
+            if (!attr_set) {
+                const int lim = 160 * 1024 - 2048 - (int)lut_bytes;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_meter_image<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_meter_image<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_meter_image<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_meter_image<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+                attr_set = true;
+            }
+            const dim3 g3(grid), b3(waves * 64u);
+            if (len) {
+                if (agg) hipLaunchKernelGGL((k_meter_image<true, true>), g3, b3, smem, s, payload, codec, len, C, done, n_frames, n, stats, agg, rank);
+                else     hipLaunchKernelGGL((k_meter_image<false, true>), g3, b3, smem, s, payload, codec, len, C, done, n_frames, n, stats, agg, rank);
+            } else {
+                if (agg) hipLaunchKernelGGL((k_meter_image<true, false>), g3, b3, smem, s, payload, codec, len, C, done, n_frames, n, stats, agg, rank);
+                else     hipLaunchKernelGGL((k_meter_image<false, false>), g3, b3, smem, s, payload, codec, len, C, done, n_frames, n, stats, agg, rank);
+            }
+        } else {
+            const uint32_t grid = blocks_for((n_frames - done + 7) / 8, 4, (uint32_t)cfg.compute_units * 8u);
+            hipLaunchKernelGGL(k_meter_wave_per_frame, dim3(grid), dim3(256), 0, s, payload, codec, len, C, done, n_frames, n, stats, pcm, agg, rank);
+        }
     }
     return hipGetLastError();
 }
@@ -2461,14 +2680,17 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
         const int waves = kernel_variant == 4 ? kRtWaves : kRtlWaves;
         const uint32_t want = (uint32_t)cfg.compute_units * (uint32_t)waves;
         uint32_t n_seg = n_groups >= want ? 1u : (want + n_groups - 1u) / n_groups;
+        if (const char *e = std::getenv("IGDSP_RT_NSEG")) n_seg = (uint32_t)std::max(1, std::atoi(e));   // experiments
         n_seg = std::max(1u, std::min(n_seg, std::max(1u, F / 8u)));
+        uint32_t order = 0;
+        if (const char *e = std::getenv("IGDSP_RT_ORDER")) order = (uint32_t)std::atoi(e);
         const uint32_t grid = blocks_for((uint64_t)n_groups * n_seg, waves, (uint32_t)cfg.compute_units);
         if (kernel_variant == 4) {
             if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_G191>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);
             else                           hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_SUN16>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);
         } else {
-            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_lut64<IGDSP_ENC_G191>), dim3(grid), dim3(kRtlWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);
-            else                           hipLaunchKernelGGL((k_roundtrip_lut64<IGDSP_ENC_SUN16>), dim3(grid), dim3(kRtlWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);
+            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_lut64<IGDSP_ENC_G191>), dim3(grid), dim3(kRtlWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups, order);
+            else                           hipLaunchKernelGGL((k_roundtrip_lut64<IGDSP_ENC_SUN16>), dim3(grid), dim3(kRtlWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups, order);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

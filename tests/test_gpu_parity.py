@@ -105,6 +105,32 @@ def test_ragged_lengths_and_odd_frame_sizes(ctx, orc, n):
     gu.assert_stats_equal(st, est, n=n)
 
 
+@pytest.mark.parametrize("n", [4, 24, 80, 164, 240, 256, 160])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_other_frame_sizes_image_kernel(ctx, orc, n, ragged):
+    """Frame sizes other than 160 (the reference's hook anticipates 164 and 24, roip_ed137.cpp:6561-6562) and ragged frames
+    no longer fall to the wave-per-frame kernel: k_meter_image meters one frame per lane from an LDS image of 64 frames.
+    Whole items, a tail item, channel wrap inside an item, mixed laws, edge frames, the aggregate; every record against the
+    oracle (160 with lengths exercises the same kernel: the tuned path takes dense frames only)."""
+    if n == 160 and not ragged:
+        pytest.skip("dense 160-byte frames are the tuned kernel's (tested above)")
+    C_, F_ = 150, 7                                  # 1050 frames = 16 items + a tail of 26
+    payload = orc.gen_uniform(F_ * C_ * n, seed=n).reshape(F_, C_, n).copy()
+    for k, fr in enumerate(_edge_frames(n)):
+        payload[k % F_, (13 * k) % C_] = fr
+    codec = np.where((np.arange(C_) * 7) % 5 < 2, 8, 0).astype(np.uint8)
+    rng = np.random.default_rng(n)
+    length = rng.integers(0, n + 1, size=(F_, C_)).astype(np.uint16) if ragged else None
+    if ragged:
+        length[0, :8] = [0, 1, 2, 3, n, max(n - 1, 0), min(49, n), min(48, n)]
+    st, _, agg = gu.run_decode_meter(ctx, payload, codec, length=length, want_agg=True, rank=5)
+    est, eagg = orc.decode_meter(payload, codec, length=length, want_agg=True, rank=5)
+    gu.assert_stats_equal(st, est, n=length if ragged else n)
+    for f in ("sumsq", "samples", "frames", "n_silent", "n_clipped", "byte_mean_sum"):
+        assert int(agg[f]) == int(eagg[f]), f
+    assert agg["peak_slot"].tolist() == eagg["peak_slot"].tolist()
+
+
 def test_config1_golden_fixture_through_gpu(ctx, golden_dir):
     """4 ch x 50 frames of the committed fixture: GPU vs values derived from audioop (not our oracle)."""
     g = np.load(os.path.join(golden_dir, "config1_4ch_50f.npz"))
