@@ -345,3 +345,56 @@ def test_fused_packed_packets_mixed_headers(ctx, orc, stride, C_, F_):
     p_ = d_st.data_ptr()
     assert ctx.L.igdsp_decode_meter_packets_mixed(ctx.h, p_, None, p_, None, 64, 1, 180, p_, None, None, 0, None) == -22   # radio missing
     assert ctx.L.igdsp_decode_meter_packets_mixed(ctx.h, p_, None, p_, p_, 64, 1, 176, p_, None, None, 0, None) == -22    # stride < 180
+
+
+def test_fuzz_fused_packets_against_two_step_route(ctx, orc):
+    """40 random cases of the fused packet entries (slot form, packed form with 12- / 20-byte headers and strides 172..256,
+    mixed headers): random sizes incl. runts, short payloads of every length, keep-alives, foreign PTs, PT / codec mismatch.
+    Each must equal the oracle's depayload followed by the oracle's meter over (payload, len)."""
+    torch = gu.torch_cuda()
+    rng = np.random.default_rng(4242)
+    n = 160
+    for case in range(40):
+        form = int(rng.integers(0, 3))                                  # 0 slots, 1 packed single header, 2 packed mixed
+        C_ = int(rng.choice([64, 128, 192, 320]))
+        F_ = int(rng.integers(1, 4))
+        hdr = 20 if form == 0 else int(rng.choice([12, 20]))
+        stride = 180 if form == 0 else int(rng.choice([hdr + 160, 180, 184, 200, 256]))
+        stride = max(stride, 180 if form == 2 else hdr + 160)
+        radio = np.ones((C_,), np.uint8) if form == 0 else (np.full((C_,), hdr == 20, np.uint8) if form == 1 else rng.integers(0, 2, C_).astype(np.uint8))
+        codec = rng.choice(np.array([0, 8], np.uint8), size=C_)
+        pk = orc.gen_uniform(F_ * C_ * stride, seed=900 + case).reshape(F_, C_, stride).copy()
+        sizes = np.zeros((F_, C_), np.uint16)
+        for f in range(F_):
+            for c in range(C_):
+                h = 20 if radio[c] else 12
+                kind = int(rng.integers(0, 12))
+                pt = int(codec[c]) if kind < 8 else [123, 18, 8 - int(codec[c]), 96][kind - 8]
+                plen = n if kind < 5 else (int(rng.integers(1, n)) if kind < 8 else int(rng.choice([0, 24, n])))
+                pkt = bytearray(hu.rtp_packet(pt, f, bytes(pk[f, c, h:h + plen]), bool(radio[c]), int(rng.integers(0, 2 ** 32))))
+                if rng.integers(0, 8) == 0:
+                    pkt[1] |= 0x80
+                pk[f, c, :len(pkt)] = np.frombuffer(bytes(pkt), np.uint8)
+                sizes[f, c] = len(pkt) if rng.integers(0, 15) else int(rng.integers(0, h))
+        d_st, d_info, d_agg = gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.dev_zeros(F_ * C_ * 8, 0xEE), gu.dev_zeros(capi.AGGREGATE.itemsize)
+        if form == 0:
+            ctx.decode_meter_rtp(gu.to_dev(_to_slots(pk, sizes)), gu.to_dev(codec), C_, F_, d_st, info=d_info, agg=d_agg, rank=case % 8)
+        elif form == 1:
+            ctx.decode_meter_packets(gu.to_dev(pk), gu.to_dev(sizes), gu.to_dev(codec), C_, F_, stride, hdr, d_st, info=d_info, agg=d_agg, rank=case % 8)
+        else:
+            ctx.decode_meter_packets_mixed(gu.to_dev(pk), gu.to_dev(sizes), gu.to_dev(codec), gu.to_dev(radio), C_, F_, stride, d_st, info=d_info, agg=d_agg, rank=case % 8)
+        torch.cuda.synchronize()
+        epl, elen, einfo = orc.depayload(pk, sizes, radio, n)
+        ginfo = gu.to_host(d_info, capi.RTP_INFO, (F_, C_))
+        for fld in capi.RTP_INFO.names:
+            assert np.array_equal(ginfo[fld], einfo[fld]), (case, fld)
+        metered = (elen > 0) & (einfo["pt"] == codec[None, :])
+        est = orc.decode_meter(epl, codec, length=elen)
+        gst = gu.to_host(d_st, capi.FRAME_STATS, (F_, C_))
+        if metered.any():
+            gu.assert_stats_equal(gst[metered].reshape(1, -1), est[metered].reshape(1, -1), n=elen[metered].reshape(1, -1))
+        assert np.all(gst[~metered]["flags"] == capi.FLAG_EMPTY), case
+        agg = gu.to_host(d_agg, capi.AGGREGATE)[0]
+        assert int(agg["frames"]) == int(metered.sum()) and int(agg["samples"]) == int(elen[metered].sum()), case
+        assert int(agg["sumsq"]) == int(est["sumsq"][metered].sum(dtype=np.uint64)), case
+        assert int(agg["peak_slot"][case % 8]) == (int(est["peak"][metered].max()) if metered.any() else 0), case

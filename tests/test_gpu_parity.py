@@ -660,6 +660,42 @@ def test_fuzz_shapes_against_oracle(ctx, orc):
     ctx.set_variant(0)
 
 
+def test_fuzz_roundtrip_shapes_against_oracle(ctx, orc):
+    """60 random (C, F, n, law mix, gates, pre-existing hold, encoder lineage, fused-kernel form) cases of
+    igdsp_roundtrip_peakhold: channel counts around the 64-channel group boundary, frame counts around the segment split,
+    n = 160 and the other reference sizes."""
+    torch = gu.torch_cuda()
+    rng = np.random.default_rng(77)
+    for case in range(60):
+        n = int(rng.choice([160, 160, 160, 164, 24, 80, 7, 256]))
+        C_ = int(rng.choice([1, 4, 63, 64, 65, 127, 128, 129, 192, 300, 640]))
+        F_ = int(rng.choice([1, 2, 7, 8, 9, 16, 33, 70]))
+        codec = rng.choice(np.array([0, 8], np.uint8), size=C_)
+        payload = orc.gen_uniform(F_ * C_ * n, seed=5000 + case).reshape(F_, C_, n).copy()
+        if rng.integers(0, 2):
+            payload[rng.integers(0, F_), rng.integers(0, C_)] = rng.choice([0xFF, 0xD5, 0x00, 0x2A, 0x7F, 0x80])
+        gate = (rng.integers(0, 3, C_) != 0).astype(np.uint8) if rng.integers(0, 2) else None
+        hold0 = gu.new_hold(C_)
+        hold0["count"] = rng.integers(0, 5, C_)
+        hold0["peak_hold"] = rng.integers(0, 32000, C_)
+        hold0["level_min"] = rng.integers(0, 256, C_)
+        variant, kernel = int(rng.integers(0, 2)), int(rng.choice([0, 0, 4, 1]))
+        d_out, d_st, d_hold = gu.dev_zeros(F_ * C_ * n, 0xEE), gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.to_dev(hold0)
+        ctx.set_variant(kernel)
+        try:
+            ctx.roundtrip_peakhold(gu.to_dev(payload), gu.to_dev(codec), C_, F_, n, d_out, d_st, d_hold,
+                                   gate=None if gate is None else gu.to_dev(gate), variant=variant)
+            torch.cuda.synchronize()
+        finally:
+            ctx.set_variant(0)
+        eout, est, ehold = orc.roundtrip_peakhold(payload, codec, hold0.copy().view(orc.CHAN_HOLD), gate=gate, variant=variant)
+        assert np.array_equal(gu.to_host(d_out, np.uint8, (F_, C_, n)), eout), case
+        gu.assert_stats_equal(gu.to_host(d_st, capi.FRAME_STATS, (F_, C_)), est, n=n)
+        ghold = gu.to_host(d_hold, capi.CHAN_HOLD)
+        for f in capi.CHAN_HOLD.names:
+            assert np.array_equal(ghold[f], ehold[f]), (case, f)
+
+
 # ----------------------------------------------------------------------------- sharding (config #4 shape)
 def test_channel_sharding_invariance(ctx, orc):
     """BASELINE configs[3] logic on one GPU: the G ranks' shards (contiguous channel ranges of the global
