@@ -42,6 +42,7 @@ BYTES_PER_SAMPLE = {"meter": (160 + 1 + 16) / 160.0, "store": (160 + 1 + 16 + 32
                     "depayload": (180 + 160 + 2 + 8) / 160.0,
                     "rtp": (192 + 1 + 16 + 8) / 160.0,           # fused: 192 B packet slot in, record + info out
                     "packets": (180 + 1 + 16 + 8) / 160.0,       # fused, packets packed at their natural 180 B stride
+                    "wav": (160 + 320) / 160.0,                  # 8(f) rank 2: payload in, [b, 0x00] file images out (+ 44 B per channel)
                     "encode": (320 + 1 + 160) / 160.0}           # a2: int16 in, code out    # 8(f) rank 1: 180 B packet in, dense payload + len + info out
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
@@ -59,7 +60,7 @@ def parse():
     ap.add_argument("--total-channels", type=int, default=0,
                     help="strong scaling: this many channels in total, split evenly over the ranks (SURVEY 8d: 524288 over 1/2/4/8 "
                          "GPUs); overrides --channels and reports \"scaling\": \"strong\"")
-    ap.add_argument("--mode", choices=["meter", "store", "roundtrip", "depayload", "rtp", "packets", "encode"], default="meter")
+    ap.add_argument("--mode", choices=["meter", "store", "roundtrip", "depayload", "rtp", "packets", "encode", "wav"], default="meter")
     ap.add_argument("--variant", type=int, default=0,
                     help="igdsp_set_variant: 0 tuned default, 1 wave-per-frame, 2 chunk64, 3 chunk64 fat waves, 4 round trip through the compressor cell table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -71,6 +72,7 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="untimed launches of the step before the W warmup steps until this much GPU time has passed: the "
                          "GPU needs ~20 ms of load to reach its steady clocks (first 30 launches measure ~6 %% slow)")
+    ap.add_argument("--wav-offset", type=int, default=84, help="wav mode: byte offset of file 0 inside its buffer (84: data bytes line-aligned; 0: headers line-aligned)")
     ap.add_argument("--placement", choices=["both", "abi", "plain"], default="both",
                     help="both: headline on igdsp_io_alloc buffers + the unassisted figure on plain igdsp_dev_alloc buffers; "
                          "abi / plain: only that one (plain = the headline itself runs on plain buffers)")
@@ -182,8 +184,11 @@ def main():
     U8, I16, I64 = torch.uint8, torch.int16, torch.int64
     MODE = args.mode
     spec = []                                    # (name, shape, dtype, role)
-    if MODE in ("meter", "store", "roundtrip"):
+    if MODE in ("meter", "store", "roundtrip", "wav"):
         spec.append(("pl", (F_, C_, n), U8, capi.IO_INPUT))
+    wav_stride = (44 + 2 * F_ * n + 127) // 128 * 128
+    if MODE == "wav":
+        spec.append(("files", (C_ * wav_stride + 128,), U8, capi.IO_BULK))
     if MODE == "depayload":
         spec.append(("pk", (F_, C_, 180), U8, capi.IO_INPUT))
     if MODE == "encode":
@@ -192,7 +197,7 @@ def main():
         spec.append(("slots", (F_, C_, 192), U8, capi.IO_INPUT))
     if MODE == "packets":
         spec.append(("slots", (F_, C_, 180), U8, capi.IO_INPUT))
-    if MODE != "encode":
+    if MODE not in ("encode", "wav"):
         spec.append(("st", (F_ * C_ * 2,), I64, capi.IO_RECORD))               # igdsp_frame_stats[F][C]
     if MODE in ("rtp", "packets", "depayload"):
         spec.append(("info", (F_ * C_,), I64, capi.IO_RECORD))
@@ -287,6 +292,9 @@ def main():
         t = B.t
         if MODE == "encode":
             ctx.encode(t["pcm_in"], d_cd, C_, F_, n, t["out"], stream=hs)
+        elif MODE == "wav":
+            # file images start 84 bytes into the buffer: base + 84 + 44 = the payload-derived bytes of every file are 128-byte aligned
+            ctx.wav_expand(t["pl"], C_, F_, n, t["files"].data_ptr() + args.wav_offset, wav_stride, stream=hs)
         elif MODE == "rtp":
             ctx.decode_meter_rtp(t["slots"], d_cd, C_, F_, t["st"], info=t["info"], agg=agg, rank=rank, stream=hs)
         elif MODE == "packets":
@@ -390,7 +398,7 @@ def main():
     value = total_samples / dt / 1e6
     bps = BYTES_PER_SAMPLE[args.mode] if n == N_SAMPLES else (n + 1 + 16) / n
     achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9
-    kernel_name = "k_encode_lut16" if args.mode == "encode" else "k_meter_rtp64" if args.mode in ("rtp", "packets") else "k_depayload64" if args.mode == "depayload" else ("k_roundtrip_chunk64" if args.variant == 4 else "k_roundtrip_lut64") if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64" if n == N_SAMPLES else "k_meter_image")
+    kernel_name = "k_encode_lut16" if args.mode == "encode" else "k_wav_expand16" if args.mode == "wav" else "k_meter_rtp64" if args.mode in ("rtp", "packets") else "k_depayload64" if args.mode == "depayload" else ("k_roundtrip_chunk64" if args.variant == 4 else "k_roundtrip_lut64") if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64" if n == N_SAMPLES else "k_meter_image")
 
     out = {
         "metric": "Msamples/s G.711 decode+RMS, 65536ch@8kHz; %HBM roofline at 1/2/4/8 GPU",

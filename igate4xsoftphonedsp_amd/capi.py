@@ -105,6 +105,7 @@ PROTOTYPES = [
     ("igdsp_decode_meter_rtp", _int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
     ("igdsp_decode_meter_packets", _int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
     ("igdsp_decode_meter_packets_mixed", _int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
+    ("igdsp_wav_expand", _int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _u64, _vp]),
     ("igdsp_g726_reorder", _int, [_vp, _vp, _vp, _u64, _int, _vp]),
     ("igdsp_gen_uniform", _int, [_vp, _vp, _u64, _u64, _u64, _vp]),
     ("igdsp_dev_alloc", _int, [_vp, C.POINTER(_vp), C.c_size_t]),
@@ -278,6 +279,9 @@ class Context:
     def decode_meter_packets_mixed(self, packets, sizes, codec, radio, C_, F_, stride, stats, info=None, agg=None, rank=0, stream=None):
         self._ck(self.L.igdsp_decode_meter_packets_mixed(self.h, _ptr(packets), _ptr(sizes), _ptr(codec), _ptr(radio), C_, F_, stride,
                                                          _ptr(stats), _ptr(info), _ptr(agg), rank, stream), "igdsp_decode_meter_packets_mixed")
+
+    def wav_expand(self, payload, C_, F_, n, files, file_stride, rate=8000, stream=None):
+        self._ck(self.L.igdsp_wav_expand(self.h, _ptr(payload), C_, F_, n, rate, _ptr(files), file_stride, stream), "igdsp_wav_expand")
 
     def g726_reorder(self, d_in, d_out, n_bytes, mode, stream=None):
         self._ck(self.L.igdsp_g726_reorder(self.h, _ptr(d_in), _ptr(d_out), n_bytes, mode, stream), "igdsp_g726_reorder")

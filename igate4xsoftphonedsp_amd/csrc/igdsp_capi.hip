@@ -477,6 +477,20 @@ int igdsp_decode_meter_packets_mixed(igdsp_ctx *ctx, const uint8_t *d_packets, c
 }
 
 
+int igdsp_wav_expand(igdsp_ctx *ctx, const uint8_t *d_payload, uint32_t C, uint32_t F, uint32_t n, uint32_t rate,
+                     uint8_t *d_files, uint64_t file_stride, void *stream)
+{
+    if (!ctx) return IGDSP_EINVAL;
+    if ((uint64_t)C * F == 0) return IGDSP_OK;
+    if (!d_payload || !d_files) return IGDSP_EINVAL;
+    if (int rc = check_shape(C, F, n)) return rc;
+    const uint64_t file_bytes = 44ull + 2ull * F * n;
+    if (file_stride < file_bytes || 2ull * F * n > 0xFFFFFFFFull - 36ull) return IGDSP_EINVAL;   // the header's sizes are 32-bit
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_wav_expand(cfg_of(ctx), d_payload, C, F, n, rate, d_files, file_stride, pick(ctx, stream)));
+    return IGDSP_OK;
+}
+
 int igdsp_g726_reorder(igdsp_ctx *ctx, const uint8_t *d_in, uint8_t *d_out, uint64_t n_bytes, int mode, void *stream)
 {
     if (!ctx || mode < 1 || mode > 4) return IGDSP_EINVAL;

@@ -49,6 +49,8 @@ hipError_t launch_hold_reset(igdsp_chan_hold *hold, uint32_t C, const uint8_t *m
 hipError_t launch_depayload(const LaunchCfg &cfg, const uint8_t *packets, const uint16_t *sizes, const uint8_t *radio,
                             uint32_t C, uint32_t F, uint32_t stride, uint32_t n, uint8_t *payload, uint16_t *len,
                             igdsp_rtp_info *info, hipStream_t s);
+hipError_t launch_wav_expand(const LaunchCfg &cfg, const uint8_t *payload, uint32_t C, uint32_t F, uint32_t n, uint32_t rate,
+                             uint8_t *files, uint64_t file_stride, hipStream_t s);
 hipError_t launch_g726(const LaunchCfg &cfg, const uint8_t *in, uint8_t *out, uint64_t n_bytes, int mode, hipStream_t s);
 hipError_t launch_gen_uniform(uint8_t *out, uint64_t n_bytes, uint64_t seed, uint64_t first_byte, hipStream_t s);
 hipError_t launch_stream_rw(const LaunchCfg &cfg, const void *src, size_t bytes, void *dst, hipStream_t s);

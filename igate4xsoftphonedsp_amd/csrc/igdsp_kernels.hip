@@ -2285,6 +2285,120 @@ __global__ __launch_bounds__(256) void k_depayload_bytes(const uint8_t *__restri
 }
 
 // ============================================================================
+// SURVEY 8(f) rank 2 on the device — recorder-compatible output (WavWriter.cpp:63-156).  For every channel c one
+// complete WavWriter file image: the 44-byte header WavWriter::start writes (tag 7, "2 channels", 16 bit, rate, rate * 4,
+// align 4) with the two sizes WavWriter::stop patches in, then every payload byte b as the two bytes [b, 0x00]
+// (write_little_endian with the channel count used as the byte count).  A [F][C][n] -> [C][44 + 2 F n] transposition
+// with a 1 : 2 byte expansion: a block stages a tile of 16 channels x 16 frames in LDS (reads: 16 n contiguous bytes per
+// frame row), then each wave streams whole channels out, 1 KiB of contiguous file bytes per store instruction.
+// ============================================================================
+constexpr int kWavTile = 16;
+
+__device__ __forceinline__ void wav_header_words(uint32_t (&h)[11], uint32_t rate, uint32_t data_bytes)
+{
+    h[0] = 0x46464952u;                  // "RIFF"
+    h[1] = 36u + data_bytes;
+    h[2] = 0x45564157u;                  // "WAVE"
+    h[3] = 0x20746D66u;                  // "fmt "
+    h[4] = 16u;
+    h[5] = 0x0007u | (2u << 16);         // format tag 7, "channels" 2
+    h[6] = rate;
+    h[7] = rate * 4u;
+    h[8] = 4u | (16u << 16);             // block align 4, 16 bits per sample
+    h[9] = 0x61746164u;                  // "data"
+    h[10] = data_bytes;
+}
+
+typedef uint32_t u32x4_st4_t __attribute__((ext_vector_type(4), aligned(4)));
+
+// n % 8 == 0: output pieces of 16 bytes (8 payload bytes) never straddle a frame
+__global__ __launch_bounds__(256) void k_wav_expand16(const uint8_t *__restrict__ payload, uint32_t C, uint32_t F, uint32_t n,
+                                                      uint32_t rate, uint8_t *__restrict__ files, uint64_t file_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t wav_tile[];     // [frame row][16 n]
+    // channel tiles are visited alternately from the two halves of the channel range: the file images of the low and the high
+    // channels are the two halves of the output buffer, which igdsp_io_alloc puts into two different classes of device memory
+    const uint32_t c0 = spread_batch(blockIdx.x, gridDim.x) * (uint32_t)kWavTile, f0 = blockIdx.y * (uint32_t)kWavTile;
+    const uint32_t nc = min((uint32_t)kWavTile, C - c0), nf = min((uint32_t)kWavTile, F - f0);
+    const uint32_t row_bytes = nc * n;                                    // bytes of this tile in one frame row (multiple of 8)
+    const uint32_t row_lds = (uint32_t)kWavTile * n;
+    // read: rows of nc * n contiguous bytes, 16 bytes per lane at dword alignment (the last piece of a row may be 8 bytes)
+    const uint32_t ppr = (row_bytes + 15u) >> 4;
+    for (uint32_t p = threadIdx.x; p < nf * ppr; p += blockDim.x) {
+        const uint32_t r = p / ppr, k = p - r * ppr;
+        const uint8_t *src = payload + ((uint64_t)(f0 + r) * C + c0) * n + 16u * k;
+        uint4 v;
+        if (16u * k + 16u <= row_bytes) v = ld16_dw(src);
+        else { const uint2 t = *reinterpret_cast<const uint2 *>(src); v = make_uint4(t.x, t.y, 0u, 0u); }
+        *reinterpret_cast<uint4 *>(wav_tile + r * row_lds + 16u * k) = v;
+    }
+    __syncthreads();
+    // write: channel by channel, consecutive lanes = consecutive 16-byte pieces of the file
+    const uint32_t ppc = nf * n / 8u;                                     // output pieces per channel in this tile
+    const uint32_t data_bytes = 2u * F * n;
+    for (uint32_t p = threadIdx.x; p < nc * ppc; p += blockDim.x) {
+        const uint32_t c = p / ppc, j = p - c * ppc;
+        const uint32_t b = 8u * j, r = b / n, i = b - r * n;
+        const uint2 t = *reinterpret_cast<const uint2 *>(wav_tile + r * row_lds + c * n + i);
+        u32x4_st4_t o;
+        o.x = __builtin_amdgcn_perm(0u, t.x, 0x0C010C00u); o.y = __builtin_amdgcn_perm(0u, t.x, 0x0C030C02u);
+        o.z = __builtin_amdgcn_perm(0u, t.y, 0x0C010C00u); o.w = __builtin_amdgcn_perm(0u, t.y, 0x0C030C02u);
+        uint8_t *dst = files + (uint64_t)(c0 + c) * file_stride + 44u + 2ull * ((uint64_t)f0 * n + b);
+        *reinterpret_cast<u32x4_st4_t *>(dst) = o;
+    }
+    if (blockIdx.y == 0 && threadIdx.x < nc * 11u) {                      // the tile of the first frames also writes the headers
+        uint32_t h[11];
+        wav_header_words(h, rate, data_bytes);
+        const uint32_t c = threadIdx.x / 11u, w = threadIdx.x - c * 11u;
+        uint32_t v = h[0];
+#pragma unroll
+        for (int q = 1; q < 11; ++q) v = (w == (uint32_t)q) ? h[q] : v;
+        reinterpret_cast<uint32_t *>(files + (uint64_t)(c0 + c) * file_stride)[w] = v;
+    }
+}
+
+// any n, any alignment: one thread per payload byte
+__global__ __launch_bounds__(256) void k_wav_expand_bytes(const uint8_t *__restrict__ payload, uint32_t C, uint32_t F, uint32_t n,
+                                                          uint32_t rate, uint8_t *__restrict__ files, uint64_t file_stride)
+{
+    const uint64_t per_ch = (uint64_t)F * n, total = per_ch * C;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = (uint32_t)(g / per_ch);
+        const uint64_t k = g - (uint64_t)c * per_ch;                      // payload byte k of channel c: frame k / n, byte k % n
+        const uint32_t f = (uint32_t)(k / n), i = (uint32_t)(k - (uint64_t)f * n);
+        const uint8_t b = payload[((uint64_t)f * C + c) * n + i];
+        uint8_t *dst = files + (uint64_t)c * file_stride + 44u + 2ull * k;
+        dst[0] = b; dst[1] = 0;
+    }
+    const uint32_t data_bytes = 2u * F * n;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < C * 44u; t += gridDim.x * blockDim.x) {
+        uint32_t h[11];
+        wav_header_words(h, rate, data_bytes);
+        const uint32_t c = t / 44u, o = t - c * 44u;
+        uint32_t v = h[0];
+#pragma unroll
+        for (int q = 1; q < 11; ++q) v = ((o >> 2) == (uint32_t)q) ? h[q] : v;
+        files[(uint64_t)c * file_stride + o] = (uint8_t)(v >> (8u * (o & 3u)));
+    }
+}
+
+hipError_t launch_wav_expand(const LaunchCfg &cfg, const uint8_t *payload, uint32_t C, uint32_t F, uint32_t n, uint32_t rate,
+                             uint8_t *files, uint64_t file_stride, hipStream_t s)
+{
+    if ((uint64_t)C * F == 0) return hipSuccess;
+    const bool fast = (n & 7u) == 0u && (file_stride & 3u) == 0u && ((reinterpret_cast<uintptr_t>(payload) | reinterpret_cast<uintptr_t>(files)) & 3u) == 0u &&
+                      (F + kWavTile - 1) / kWavTile <= 65535u;
+    if (fast) {
+        const dim3 grid((C + kWavTile - 1) / kWavTile, (F + kWavTile - 1) / kWavTile);
+        hipLaunchKernelGGL(k_wav_expand16, grid, dim3(256), (size_t)kWavTile * kWavTile * n, s, payload, C, F, n, rate, files, file_stride);
+    } else {
+        const uint64_t total = (uint64_t)C * F * n;
+        hipLaunchKernelGGL(k_wav_expand_bytes, dim3(blocks_for(total, 256, (uint32_t)cfg.compute_units * 16u)), dim3(256), 0, s, payload, C, F, n, rate, files, file_stride);
+    }
+    return hipGetLastError();
+}
+
+// ============================================================================
 // SURVEY 8(f) rank 4 — G.726 code-word reorder (changeUplinkOrder, roip_ed137.cpp:6379-6499), byte-parallel.
 // Modes 1 / 3 permute bit fields inside each byte: whole dwords with masks, 16 B per lane.
 // Modes 2 / 4 permute inside 3- / 5-byte groups: one lane takes four groups (12 / 20 bytes = 3 / 5 aligned dwords).

@@ -307,6 +307,17 @@ int igdsp_decode_meter_packets_mixed(igdsp_ctx *ctx, const uint8_t *d_packets, c
                                      igdsp_frame_stats *d_stats, igdsp_rtp_info *d_info,
                                      igdsp_aggregate *d_agg, uint32_t rank, void *stream);
 
+/* ---- recorder-compatible output on the device (WavWriter.cpp:63-156) ------------------------------
+ * The step AFTER the path.  For every channel c of a batch payload[F][C][n] one complete file image exactly as the
+ * reference's recorder would leave it after writeRTPWav(frame 0) ... writeRTPWav(frame F-1), stop():
+ *     files + c * file_stride : [ 44-byte header | every payload byte b as the two bytes {b, 0x00} ]   (44 + 2 F n bytes)
+ * header = WavWriter::start's (RIFF / WAVE / "fmt " 16, tag 7, "channels" 2, rate, rate * 4, align 4, 16 bits, "data") with
+ * the two sizes WavWriter::stop patches in (36 + 2 F n and 2 F n).  file_stride >= 44 + 2 F n; a multiple of 4 (and n % 8
+ * == 0) takes the tiled streaming kernel, anything else a byte-wise one.  Byte-identical to the host recorder
+ * (igdsp_wav_* in the host mirror) and to the REAL WavWriter.cpp (tests/golden/config1_4ch_50f.npz). */
+int igdsp_wav_expand(igdsp_ctx *ctx, const uint8_t *d_payload, uint32_t n_channels, uint32_t n_frames, uint32_t samples_per_frame,
+                     uint32_t rate, uint8_t *d_files, uint64_t file_stride, void *stream);
+
 /* ---- G.726 code-word reorder (RoIP_ED137::changeUplinkOrder, roip_ed137.cpp:6379-6499) ----
  * Repacks G.726 code words between the RFC 3551 and AAL2 bit orders, bug-for-bug as the reference
  * does it on its (unsigned-char) target:

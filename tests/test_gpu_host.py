@@ -10,6 +10,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+from igate4xsoftphonedsp_amd import capi  # noqa: E402
+from tests import gpu_util as gu  # noqa: E402
 from tests import host_util as hu  # noqa: E402
 
 
@@ -199,3 +201,71 @@ def _ctx_of(L, h):
     L.igdsp_host_ctx.restype = C.c_void_p
     L.igdsp_host_ctx.argtypes = [C.c_void_p]
     return L.igdsp_host_ctx(h)
+
+
+def _wav_expected(orc, payload, c, rate=8000):
+    F_, _, n = payload.shape
+    body = orc.wav_expand(np.ascontiguousarray(payload[:, c, :]).reshape(-1))
+    return np.concatenate([np.frombuffer(orc.wav_header(rate, body.size), np.uint8), body])
+
+
+def test_wav_expand_on_device_equals_real_wavwriter(orc, golden_dir, tmp_path):
+    """SURVEY 8(f) rank 2 on the device: igdsp_wav_expand's per-channel file images are byte-identical to (i) the files the REAL
+    WavWriter.cpp wrote for BASELINE config #1 (4 ch x 50 frames; tests/golden/config1_4ch_50f.npz), (ii) the host recorder
+    igdsp_wav_* and the oracle's restatement at 4 096 channels (every channel against the oracle, a few through real files),
+    (iii) for shapes that take the byte-wise kernel (n = 164, odd strides)."""
+    import json, hashlib
+    torch = gu.torch_cuda()
+    L = hu.load()
+    g = np.load(os.path.join(golden_dir, "config1_4ch_50f.npz"))
+    with open(os.path.join(golden_dir, "config1_4ch_50f.json")) as fh:
+        meta = json.load(fh)
+    ctx = capi.Context(device=0, max_channels=4)
+    try:
+        payload = np.ascontiguousarray(g["payload"])                     # [50][4][160]
+        F_, C_, n = payload.shape
+        stride = 44 + 2 * F_ * n
+        d_files = gu.dev_zeros(C_ * stride, 0xEE)
+        ctx.wav_expand(gu.to_dev(payload), C_, F_, n, d_files, stride)
+        torch.cuda.synchronize()
+        files = gu.to_host(d_files, np.uint8, (C_, stride))
+        for c in range(C_):
+            assert files[c].tobytes() == g[f"wav{c}"].tobytes()
+            assert hashlib.sha256(files[c].tobytes()).hexdigest() == meta["wav_sha256"][c]
+        # 4 096 channels x 16 frames, padded file stride
+        C_, F_, n = 4096, 16, 160
+        payload = orc.gen_uniform(F_ * C_ * n, seed=21).reshape(F_, C_, n)
+        stride = (44 + 2 * F_ * n + 127) // 128 * 128
+        d_files = gu.dev_zeros(C_ * stride, 0xEE)
+        ctx.wav_expand(gu.to_dev(payload), C_, F_, n, d_files, stride)
+        torch.cuda.synchronize()
+        files = gu.to_host(d_files, np.uint8, (C_, stride))
+        exp = np.zeros((C_, 2 * F_ * n), np.uint8)
+        exp[:, 0::2] = payload.transpose(1, 0, 2).reshape(C_, F_ * n)
+        assert np.array_equal(files[:, 44:44 + 2 * F_ * n], exp)
+        assert np.all(files[:, 44 + 2 * F_ * n:] == 0xEE)                  # padding untouched
+        hdr = np.frombuffer(orc.wav_header(8000, 2 * F_ * n), np.uint8)
+        assert np.array_equal(files[:, :44], np.broadcast_to(hdr, (C_, 44)))
+        for c in (0, 1, 2047, 4095):                                       # the host recorder writes the same bytes
+            path = str(tmp_path / f"h{c}.wav").encode()
+            w = L.igdsp_wav_start(path, 8000)
+            for f in range(F_):
+                assert L.igdsp_wav_writeRTPWav(w, bytes(12), payload[f, c].tobytes(), 12, n) == 0
+            assert L.igdsp_wav_stop(w) == 0
+            assert open(path, "rb").read() == files[c, :44 + 2 * F_ * n].tobytes() == _wav_expected(orc, payload, c).tobytes()
+        # shapes of the byte-wise kernel and edge tiles of the tiled one
+        for C_, F_, n, pad in [(5, 3, 164, 3), (33, 17, 24, 0), (1, 1, 1, 1), (17, 33, 160, 4), (16, 16, 256, 0)]:
+            payload = orc.gen_uniform(F_ * C_ * n, seed=C_ + n).reshape(F_, C_, n)
+            stride = 44 + 2 * F_ * n + pad
+            d_files = gu.dev_zeros(C_ * stride, 0xEE)
+            ctx.wav_expand(gu.to_dev(payload), C_, F_, n, d_files, stride, rate=16000)
+            torch.cuda.synchronize()
+            files = gu.to_host(d_files, np.uint8, (C_, stride))
+            for c in range(C_):
+                assert files[c, :44 + 2 * F_ * n].tobytes() == _wav_expected(orc, payload, c, 16000).tobytes(), (C_, F_, n, c)
+            assert np.all(files[:, 44 + 2 * F_ * n:] == 0xEE)
+        p = d_files.data_ptr()
+        assert ctx.L.igdsp_wav_expand(ctx.h, p, 4, 4, 160, 8000, p, 100, None) == -22      # stride shorter than a file
+        assert ctx.L.igdsp_wav_expand(ctx.h, None, 4, 4, 160, 8000, p, 4096, None) == -22
+    finally:
+        ctx.close()
