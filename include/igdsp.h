@@ -313,7 +313,8 @@ int igdsp_decode_meter_packets_mixed(igdsp_ctx *ctx, const uint8_t *d_packets, c
  *     files + c * file_stride : [ 44-byte header | every payload byte b as the two bytes {b, 0x00} ]   (44 + 2 F n bytes)
  * header = WavWriter::start's (RIFF / WAVE / "fmt " 16, tag 7, "channels" 2, rate, rate * 4, align 4, 16 bits, "data") with
  * the two sizes WavWriter::stop patches in (36 + 2 F n and 2 F n).  file_stride >= 44 + 2 F n; a multiple of 4 (and n % 8
- * == 0) takes the tiled streaming kernel, anything else a byte-wise one.  Byte-identical to the host recorder
+ * == 0) takes the tiled streaming kernel, anything else a byte-wise one.  Fastest (0.77 of the HBM peak instead of 0.70)
+ * when (d_files + 44) % 128 == 0 and file_stride % 128 == 0: the payload-derived bytes of every file are then line-aligned.  Byte-identical to the host recorder
  * (igdsp_wav_* in the host mirror) and to the REAL WavWriter.cpp (tests/golden/config1_4ch_50f.npz). */
 int igdsp_wav_expand(igdsp_ctx *ctx, const uint8_t *d_payload, uint32_t n_channels, uint32_t n_frames, uint32_t samples_per_frame,
                      uint32_t rate, uint8_t *d_files, uint64_t file_stride, void *stream);
@@ -341,7 +342,8 @@ int igdsp_gen_uniform(igdsp_ctx *ctx, uint8_t *d_out, uint64_t n_bytes,
  * where a stream is given. */
 int igdsp_dev_alloc(igdsp_ctx *ctx, void **d_ptr, size_t bytes);
 int igdsp_dev_free(igdsp_ctx *ctx, void *d_ptr);
-/* Allocate an OUTPUT buffer in another class of device memory than the input it will be written from (see
+/* (Round-1 helper, superseded by igdsp_io_alloc below which places a whole buffer set and also finds the third class.)
+ * Allocate an OUTPUT buffer in another class of device memory than the input it will be written from (see
  * igdsp_probe_placement): tries up to max_tries positions, each a further spacer_bytes (0 = 12 GiB) of temporary
  * allocation away, times the bare read(d_in) + write(candidate) stream for each, keeps the fastest candidate, frees the
  * rest and the spacers.  Stops early once a candidate is >= 8 % faster than the first.  ms_first / ms_kept (optional)
@@ -413,7 +415,7 @@ int igdsp_stream_read(igdsp_ctx *ctx, const void *d_src, size_t bytes, uint64_t 
 /* Placement probe.  On MI355X a stream that READS one large region of device memory and WRITES another runs ~13 %
  * faster than one that reads and writes the same region (regions are tens of GiB; inside one 80 GiB allocation the
  * bare read + record stream takes 0.218 ms across a region boundary and 0.252 ms within a region; the pure read rate
- * is the same everywhere; tools/placement_map2.py).  This call times the bare read + record-store stream
+ * is the same everywhere; tools/placement_map.py grid).  This call times the bare read + record-store stream
  * (the meter kernel's traffic, no compute) reading d_in and writing d_out (bytes / 10 are written; NULL = a scratch
  * buffer allocated for the call), so a host can place its output buffers (records, PCM, re-encoded payload) a few
  * candidate distances away from its payload ring at start-up and keep the fastest.  Synchronous: 3 + reps launches
