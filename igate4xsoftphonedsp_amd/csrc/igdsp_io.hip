@@ -405,24 +405,32 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
             if (ok && X.ensure(kSrcChunks)) { for (int k = 0; k < 28 && ok; ++k) ok = X.probe(kSrcChunks, X.sources[srcA], &t, "warm"); }
         }
         if (ok) survey(false);
-        if (ok && tmax > kBimodal * tmin && tmax < kPure * tmin) {
-            // The levels are closer than two pure classes give: source A straddles a class boundary.  Re-seed it inside the
-            // longest stretch of survey samples that sit on one level (a run of one class), and time everything again.
-            size_t best_first = 0, best_n = 0;
-            for (size_t a = 0; a < surveyed.size();) {
-                size_t b = a + 1;
-                while (b < surveyed.size() && std::fabs(X.chunks[surveyed[b]].tA - X.chunks[surveyed[a]].tA) < 0.02f * X.chunks[surveyed[a]].tA) ++b;
-                if (b - a > best_n) { best_n = b - a; best_first = surveyed[a]; }
-                a = b;
+        for (int attempt = 0; attempt < 2 && ok && tmax > 1.02f * tmin && tmax < kPure * tmin; ++attempt) {
+            // The levels are closer than two pure classes give: the ten consecutive chunks of source A mix classes (a run boundary,
+            // or memory that is interleaved chunk by chunk).  The SLOWEST destinations are pure chunks of the class the mixed source
+            // holds most of: collect ten of them — the slowest survey sample and its neighbours, then the next slowest — and make
+            // them the source.  Everything is timed again against it.
+            std::vector<size_t> order(surveyed);
+            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return X.chunks[a].tA > X.chunks[b].tA; });
+            std::vector<size_t> pick;
+            const float near_slow = tmax / 1.015f;
+            for (size_t si = 0; si < order.size() && pick.size() < kSrcChunks && ok; ++si) {
+                const size_t c0 = order[si];
+                if (X.chunks[c0].tA < near_slow) break;
+                const size_t lo = c0 >= stride ? c0 - stride + 1 : 0;
+                for (size_t k = lo; k < c0 + stride && pick.size() < kSrcChunks && ok; ++k) {
+                    if (!X.ensure(k) || X.chunks[k].in_src) continue;
+                    if (!timeA(k)) break;
+                    if (X.chunks[k].tA >= near_slow && std::find(pick.begin(), pick.end(), k) == pick.end()) pick.push_back(k);
+                }
             }
-            if (best_n >= 2) {
-                if (X.debug) std::fprintf(stderr, "[igdsp_io] levels %.4f / %.4f: source A is mixed, re-seeding at chunk %zu\n", tmax, tmin, best_first + 2);
-                X.drop_source(srcA);
-                for (auto &c : X.chunks) c.tA = -1.f;
-                ok = seed(best_first + 2);
-                if (ok) survey(true);
-                ++R.reseeds;
-            }
+            if (pick.size() < kSrcChunks) break;
+            if (X.debug) std::fprintf(stderr, "[igdsp_io] levels %.4f / %.4f: source A is mixed, re-seeding from the %zu slowest chunks (first %zu)\n", tmax, tmin, pick.size(), pick[0]);
+            X.drop_source(srcA);
+            for (auto &c : X.chunks) c.tA = -1.f;
+            ok = X.make_source(pick, &srcA);
+            if (ok) survey(true);
+            ++R.reseeds;
         }
         const bool bimodal = ok && tmax > kBimodal * tmin;
         R.probe_ms_same = tmax;

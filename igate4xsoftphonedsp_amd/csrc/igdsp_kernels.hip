@@ -63,6 +63,26 @@ __device__ __forceinline__ void st_stream(uint4 *p, const uint4 v)
 #endif
 }
 
+// Buffer-instruction form of the streaming accesses: a wave-uniform 128-bit descriptor (SGPRs) + one 32-bit lane offset
+// (lane * 16) + a scalar offset.  The compiler never forms SGPR-base addressing for global_load / global_store on this path
+// (every address is a per-lane 64-bit VGPR pair and 10 KiB spans need several of them), so the kernels that are short of
+// registers describe their windows themselves.  Raw buffer, no swizzle, 32-bit data format; the range check is switched off
+// by the largest record count (every offset used is < 2^32 because the base is re-seated per item / frame).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xFFFFFFFFu, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_ld_stream(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 2);          // aux 2 = nt
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, const uint4 v)
+{
+    u32x4_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, (int)voff, (int)soff, 0);
+}
+
 __device__ __forceinline__ uint32_t full_scale(bool alaw) { return alaw ? 32256u : 32124u; }
 
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m)
@@ -314,6 +334,7 @@ __device__ __forceinline__ uint2 lut_at(const uint2 *lut, uint32_t t, uint32_t o
 }
 
 typedef short v2i16 __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u16_t __attribute__((ext_vector_type(2)));
 
 // two magnitudes -> one dword of signed int16 PCM (codes k and k + 1 of word w; a code is negative iff its bit 7 is
 // clear).  Packed 16-bit math: one v_perm puts the two inverted sign bits at bits 15 / 31, a packed arithmetic shift
@@ -1814,11 +1835,28 @@ __device__ __forceinline__ void fill_recode_lut(uint2 *lut)
     }
 }
 
+// Per-lane piece constants of a half, packed: five 5-bit frame indices (frame-in-half of piece j) in `fr5`, five 5-bit probe
+// shifts in `pm5` (the probe byte a piece is responsible for sits at that bit of probe_fail's gathered word; 24 = none, that
+// byte of the word is always zero).  Two registers instead of ten; one v_bfe_u32 (+ one shift) per piece to unpack.
+__device__ __forceinline__ void pack_piece_consts(uint32_t lane, uint32_t &fr5, uint32_t &pm5)
+{
+    fr5 = 0; pm5 = 0;
+#pragma unroll
+    for (int j = 0; j < kLoadsPerChunk; ++j) {
+        const uint32_t p = (uint32_t)j * 64u + lane, f = p / 10u, q = p - f * 10u;
+        const uint32_t sh = q == 1u ? 0u : (q == 3u ? 8u : (q == 2u ? 16u : 24u));
+        fr5 |= f << (5 * j);
+        pm5 |= sh << (5 * j);
+    }
+}
+
 // One half (32 frames) of a super-chunk: expand, meter, re-encode.  Same software pipeline as process_half (the LUT reads
 // of unit u + 1 are in flight while unit u is folded); the eight re-encoded bytes of a unit are assembled right in its fold.
+// All memory traffic goes through buffer instructions: `rin` describes the NEXT frame's super-chunk (refill), `rout` this
+// frame's output super-chunk; `voff` = lane * 16, `hoff` = byte offset of the half inside the super-chunk.
 __device__ __forceinline__ void recode_half(const uint2 *lut, uint2 *strip_half, uint4 (&d)[kLoadsPerChunk], const uint32_t am,
-                                            const uint32_t (&fr)[kLoadsPerChunk], const uint32_t (&pm)[kLoadsPerChunk],
-                                            const uint32_t off, const uint32_t lane, uint4 *out_half, const uint4 *refill)
+                                            const uint32_t fr5, const uint32_t pm5, const uint32_t off, const uint32_t lane,
+                                            const uint32_t voff, const uint32_t hoff, __amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rout)
 {
     uint2 e[2][8];
     uint32_t wa[2], wb[2];
@@ -1826,7 +1864,8 @@ __device__ __forceinline__ void recode_half(const uint2 *lut, uint2 *strip_half,
         const int j = u >> 1, k = u & 1;
         wa[k] = (u & 1) ? d[j].z : d[j].x;
         wb[k] = (u & 1) ? d[j].w : d[j].y;
-        const uint32_t lmj = (uint32_t)__builtin_amdgcn_sbfe(am, fr[j], 1) & 0x80808080u;
+        const uint32_t frj = __builtin_amdgcn_ubfe(fr5, 5 * j, 5);
+        const uint32_t lmj = (uint32_t)__builtin_amdgcn_sbfe(am, frj, 1) & 0x80808080u;
         const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lmj, tb = (wb[k] & 0x7F7F7F7Fu) | lmj;
         e[k][0] = lut_at(lut, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lut, ta, off, 0x0C0C0500u);
         e[k][2] = lut_at(lut, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lut, ta, off, 0x0C0C0700u);
@@ -1857,9 +1896,10 @@ __device__ __forceinline__ void recode_half(const uint2 *lut, uint2 *strip_half,
         o[2 * k] = recode4(wa[k], e[k][0], e[k][1], e[k][2], e[k][3]);
         o[2 * k + 1] = recode4(wb[k], e[k][4], e[k][5], e[k][6], e[k][7]);
         if (k == 1) {
-            strip_half[j * 64 + lane] = make_uint2(sum, (peak >> 16) | (bsum << 16) | probe_fail(d[j], pm[j]));
-            st_stream(out_half + j * 64, make_uint4(o[0], o[1], o[2], o[3]));
-            d[j] = ld_stream(refill + j * 64);
+            const uint32_t pmj = 0xFFu << __builtin_amdgcn_ubfe(pm5, 5 * j, 5);
+            strip_half[j * 64 + lane] = make_uint2(sum, (peak >> 16) | (bsum << 16) | probe_fail(d[j], pmj));
+            buf_st(rout, voff, hoff + (uint32_t)j * 1024u, make_uint4(o[0], o[1], o[2], o[3]));
+            d[j] = buf_ld_stream(rin, voff, hoff + (uint32_t)j * 1024u);
             sum = 0; peak = 0; bsum = 0;
         }
     }
@@ -1878,18 +1918,13 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_lut64(
     fill_recode_lut<VARIANT>(lds);
     __syncthreads();
 
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint2 *strip = lds + kLutEntries + wave * kStripEntries;
-    const uint32_t off = (lane & 31u) * 8u;
-    uint32_t fr[kLoadsPerChunk], pm[kLoadsPerChunk];
-#pragma unroll
-    for (int j = 0; j < kLoadsPerChunk; ++j) {
-        const uint32_t p = (uint32_t)j * 64u + lane;
-        fr[j] = p / 10u;
-        pm[j] = probe_mask(p - fr[j] * 10u);
-    }
+    const uint32_t off = (lane & 31u) * 8u, voff = lane * 16u;
+    uint32_t fr5, pm5;
+    pack_piece_consts(lane, fr5, pm5);
     const uint32_t total_waves = gridDim.x * kRtlWaves;
-    const uint32_t fstride16 = C * (uint32_t)kPiecesPerFrame;       // uint4 units between frames of one channel group
+    const uint64_t fbytes = (uint64_t)C * kFrame;                  // bytes between two frames of one channel group
 
     // order 0: the waves of a block take items a grid apart (neighbouring BLOCKS touch neighbouring groups); order 1: the
     // waves of a block take consecutive items (one block touches kRtlWaves neighbouring groups = 120 KiB per frame)
@@ -1901,54 +1936,66 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_lut64(
         const uint32_t c0 = cg * kSuperFrames, cme = c0 + lane;
         const bool my_alaw = codec[cme] == IGDSP_PT_PCMA;
         const bool open = (gate == nullptr) || (gate[cme] != 0);
-        igdsp_chan_hold h;
-        if (n_seg == 1u) h = hold[cme];
-        else { h.sumsq_acc = 0; h.count = 0; h.level_sum = 0; h.samples = 0; h.peak_hold = 0; h.level_max = 0; h.level_min = 255; h.n_silent = 0; h.n_clipped = 0; }
+        // the window of this item, packed: {peak_hold | level_max << 16} (packed 16-bit max), level_min, {n_silent | n_clipped << 16}
+        // (a segment never has 65 536 frames: launcher), level_sum, sumsq; count = frames of the segment if the gate is open
+        uint64_t h_sumsq = 0;
+        uint32_t h_pm = 0, h_min = 255u, h_sc = 0, h_lsum = 0;
         const uint64_t amask = __ballot(my_alaw);
         const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
-        const uint4 *src = reinterpret_cast<const uint4 *>(payload) + ((uint64_t)c0 * kPiecesPerFrame + lane);
-        uint4 *dst = reinterpret_cast<uint4 *>(out) + ((uint64_t)c0 * kPiecesPerFrame + lane);
+        const uint8_t *in0 = payload + (uint64_t)c0 * kFrame;     // wave-uniform bases: frame f of this group sits f * fbytes further
+        uint8_t *out0 = out + (uint64_t)c0 * kFrame;
 
         uint4 X[kLoadsPerChunk], Y[kLoadsPerChunk];
+        {
+            const __amdgpu_buffer_rsrc_t r0 = make_rsrc(in0 + (uint64_t)f_lo * fbytes);
 #pragma unroll
-        for (int j = 0; j < kLoadsPerChunk; ++j) X[j] = ld_stream(src + (uint64_t)f_lo * fstride16 + j * 64);
+            for (int j = 0; j < kLoadsPerChunk; ++j) X[j] = buf_ld_stream(r0, voff, (uint32_t)j * 1024u);
 #pragma unroll
-        for (int j = 0; j < kLoadsPerChunk; ++j) Y[j] = ld_stream(src + (uint64_t)f_lo * fstride16 + kPiecesPerChunk + j * 64);
-
+            for (int j = 0; j < kLoadsPerChunk; ++j) Y[j] = buf_ld_stream(r0, voff, (uint32_t)kChunkBytes + (uint32_t)j * 1024u);
+        }
         for (uint32_t f = f_lo; f < f_hi; ++f) {
             const bool more = f + 1u < f_hi;                    // wave-uniform; the last frame re-reads itself (cache hit)
-            const uint4 *nsrc = src + (uint64_t)(more ? f + 1u : f) * fstride16;
-            uint4 *o16 = dst + (uint64_t)f * fstride16;
-            recode_half(lds, strip, X, am_lo, fr, pm, off, lane, o16, nsrc);
-            recode_half(lds, strip + kPiecesPerChunk, Y, am_hi, fr, pm, off, lane, o16 + kPiecesPerChunk, nsrc + kPiecesPerChunk);
+            const __amdgpu_buffer_rsrc_t rin = make_rsrc(in0 + (uint64_t)(more ? f + 1u : f) * fbytes);
+            const __amdgpu_buffer_rsrc_t rout = make_rsrc(out0 + (uint64_t)f * fbytes);
+            recode_half(lds, strip, X, am_lo, fr5, pm5, off, lane, voff, 0u, rin, rout);
+            recode_half(lds, strip + kPiecesPerChunk, Y, am_hi, fr5, pm5, off, lane, voff, (uint32_t)kChunkBytes, rin, rout);
             wave_lds_fence();
             {
                 const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kPiecesPerFrame);
-                uint64_t s = 0;
+                uint64_t sq = 0;
                 uint32_t peak = 0, bsum = 0, fail = 0;
 #pragma unroll
                 for (int i = 0; i < kPiecesPerFrame / 2; ++i) {
                     const uint4 v = row[i];
-                    s += (uint64_t)(v.x + v.z);
+                    sq += (uint64_t)(v.x + v.z);
                     peak = max(max(peak, v.y & 0x7FFFu), v.w & 0x7FFFu);
                     bsum += ((v.y >> 16) & 0x7FFFu) + ((v.w >> 16) & 0x7FFFu);
                     fail |= v.y | v.w;
                 }
                 uint32_t bm, fl;
-                st_stream(reinterpret_cast<uint4 *>(stats + ((uint64_t)f * C + cme)), pack_stats160(s, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl));
-                if (open) {
-                    h.sumsq_acc += s << 4; h.count += 1u; h.level_sum += bm; h.samples += (uint32_t)kFrame;
-                    h.peak_hold = (uint16_t)max((uint32_t)h.peak_hold, peak);
-                    h.level_max = (uint8_t)max((uint32_t)h.level_max, bm);
-                    h.level_min = (uint8_t)min((uint32_t)h.level_min, bm);
-                    h.n_silent += (fl & IGDSP_FLAG_SILENT) ? 1u : 0u;
-                    h.n_clipped += (fl & IGDSP_FLAG_CLIPPED) ? 1u : 0u;
-                }
+                const uint4 rec = pack_stats160(sq, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl);
+                buf_st(make_rsrc(stats + ((uint64_t)f * C + c0)), voff, 0u, rec);       // 64 records = 1 KiB, lane * 16
+                h_sumsq += sq << 4; h_lsum += bm;
+                h_pm = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16_t, h_pm), __builtin_bit_cast(v2u16_t, peak | (bm << 16))));
+                h_min = min(h_min, bm);
+                h_sc += ((fl & IGDSP_FLAG_SILENT) ? 1u : 0u) + ((fl & IGDSP_FLAG_CLIPPED) ? 0x10000u : 0u);
             }
             wave_lds_fence();
         }
-        if (n_seg == 1u) hold[cme] = h;
-        else if (h.count != 0u) hold_merge(hold + cme, h);
+        if (open) {
+            igdsp_chan_hold h;
+            const uint32_t cnt = f_hi - f_lo;
+            h.sumsq_acc = h_sumsq; h.count = cnt; h.level_sum = h_lsum; h.samples = cnt * (uint32_t)kFrame;
+            h.peak_hold = (uint16_t)(h_pm & 0xFFFFu); h.level_max = (uint8_t)(h_pm >> 16); h.level_min = (uint8_t)h_min;
+            h.n_silent = h_sc & 0xFFFFu; h.n_clipped = h_sc >> 16;
+            if (n_seg == 1u) {                                   // the wave owns hold[c]: plain read-modify-write
+                igdsp_chan_hold g = hold[cme];
+                g.sumsq_acc += h.sumsq_acc; g.count += h.count; g.level_sum += h.level_sum; g.samples += h.samples;
+                g.peak_hold = max(g.peak_hold, h.peak_hold); g.level_max = max(g.level_max, h.level_max); g.level_min = min(g.level_min, h.level_min);
+                g.n_silent += h.n_silent; g.n_clipped += h.n_clipped;
+                hold[cme] = g;
+            } else hold_merge(hold + cme, h);
+        }
     }
 }
 
@@ -2796,6 +2843,7 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
         uint32_t n_seg = n_groups >= want ? 1u : (want + n_groups - 1u) / n_groups;
         if (const char *e = std::getenv("IGDSP_RT_NSEG")) n_seg = (uint32_t)std::max(1, std::atoi(e));   // experiments
         n_seg = std::max(1u, std::min(n_seg, std::max(1u, F / 8u)));
+        n_seg = std::max(n_seg, F / 65535u + 1u);               // the fused kernels count silent / clipped frames of a segment in 16 bits
         uint32_t order = 0;
         if (const char *e = std::getenv("IGDSP_RT_ORDER")) order = (uint32_t)std::atoi(e);
         const uint32_t grid = blocks_for((uint64_t)n_groups * n_seg, waves, (uint32_t)cfg.compute_units);
