@@ -1083,6 +1083,185 @@ __device__ __forceinline__ void bq_finish(uint32_t *gq, uint32_t G)             
     if (threadIdx.x == 0 && atomicAdd(gq + 1, 1u) == G - 1u) { gq[0] = 0u; gq[1] = 0u; }
 }
 
+// ============================================================================
+// The reference's other frame sizes at full speed — k_meter_strided<Q, TAIL>: k_meter_chunk64's pipeline for dense frames of
+// n = 16 Q + 4 T bytes (T = 0, 1, 2 tail dwords): Q = 10 -> 164 (the size the hook anticipates, roip_ed137.cpp:6561), 168;
+// Q = 5 -> 80 (10 ms); Q = 15 -> 240 (30 ms); Q = 1 -> 16, 20, 24 (24: the other anticipated size).  A frame no longer starts
+// on a 16-byte boundary, so piece q of frame f is fetched from f * n + 16 q with a dword-aligned 16-byte load (as the packed
+// packet kernel does) and never straddles a frame.  With a tail (TAIL) every frame has one more piece, the frame's LAST 16
+// bytes [n - 16, n): it overlaps piece Q - 1 (same cache lines, same load instruction: no extra memory traffic), rides
+// through the expansion pipeline like the header pieces of k_meter_rtp64 (1 / (Q + 1) wasted LUT work) and hands its last two
+// dwords RAW to the frame's lane through the strip; that lane expands the T tail dwords itself at fold time.  (A first
+// version let the frame lane load its tail dwords from global memory: 64 scattered 4-byte requests per item re-fetched the
+// lines — 0.48 of peak at n = 164 against 0.80 at n = 240.)  Item = 64 frames = Q + TAIL wave-wide loads, every piece
+// register re-loaded from the next item the moment it is folded; block / device work queue as in k_meter_chunk64.
+// ============================================================================
+template <int QP> struct StridedGeom { static constexpr int kWaves = QP <= 11 ? 16 : 12; };
+
+template <int Q, bool TAIL, bool AGG>
+__global__ __launch_bounds__(StridedGeom<Q + (TAIL ? 1 : 0)>::kWaves * 64) void k_meter_strided(
+    const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t n_frames, uint32_t n,
+    igdsp_frame_stats *__restrict__ stats, igdsp_aggregate *agg, uint32_t rank, uint32_t *gqueue)
+{
+    static_assert(Q == 1 || Q >= 4, "the probe bytes 28 / 38 / 48 are taken from pieces 1 / 2 / 3");
+    constexpr int QP = Q + (TAIL ? 1 : 0);                       // pieces per frame
+    constexpr int kWaves = StridedGeom<QP>::kWaves;
+    constexpr int kStrip = kSuperFrames * QP;
+    __shared__ uint2 lds[kLutEntries + kWaves * kStrip];
+    __shared__ BlockQueue<kWaves> bq;
+    uint32_t gb1 = 0;
+    if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);
+    fill_lut(lds);
+    if (threadIdx.x == 0) bq_init(bq, gqueue, gridDim.x, gb1);
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint2 *strip = lds + kLutEntries + wave * kStrip;
+    const uint32_t off = (lane & 31u) * 8u;
+    const uint32_t T = (n - 16u * Q) >> 2;                       // tail dwords per frame (TAIL: 1 or 2), wave-uniform
+    // per-lane piece constants, two pieces per register: frame of the item (6 bits) | probe shift << 8 (24 = none) | tail
+    // piece << 13, in each 16-bit half.  The byte offset of piece j inside the item follows from the frame and the piece
+    // number: f * n + (tail ? n - 16 : 16 q).
+    constexpr int kPk = (QP + 1) / 2;
+    uint32_t pk[kPk];
+#pragma unroll
+    for (int j = 0; j < kPk; ++j) pk[j] = 0;
+#pragma unroll
+    for (int j = 0; j < QP; ++j) {
+        const uint32_t p = (uint32_t)j * 64u + lane, f = p / (uint32_t)QP, q = p - f * (uint32_t)QP;
+        const uint32_t sh = q == 1u ? 0u : (q == 3u ? 8u : (q == 2u ? 16u : 24u));
+        pk[j >> 1] |= (f | (((TAIL && q == (uint32_t)Q) ? 24u : sh) << 8) | ((TAIL && q == (uint32_t)Q) ? 0x2000u : 0u)) << (16 * (j & 1));
+    }
+    auto fr_of = [&](int j) { return __builtin_amdgcn_ubfe(pk[j >> 1], 16 * (j & 1), 6); };
+    auto ps_of = [&](int j) { return __builtin_amdgcn_ubfe(pk[j >> 1], 16 * (j & 1) + 8, 5); };
+    auto tail_of = [&](int j) { return TAIL && ((pk[j >> 1] >> (16 * (j & 1) + 13)) & 1u) != 0u; };
+    auto po_of = [&](int j) {                                    // byte offset of this lane's piece j inside an item
+        const uint32_t f = fr_of(j), q = (uint32_t)j * 64u + lane - f * (uint32_t)QP;
+        return f * n + (tail_of(j) ? n - 16u : 16u * q);
+    };
+    const uint32_t G = gridDim.x;
+    const uint32_t n_super = n_frames / kSuperFrames;           // the launcher hands over whole items only
+    const uint64_t item_bytes = (uint64_t)kSuperFrames * n;
+    uint64_t a_sumsq = 0;
+    uint32_t a_bm = 0, a_peak = 0;
+    uint32_t u_frames = 0, u_sil = 0, u_clip = 0;
+    auto fetch_pt = [&](uint32_t sidx) { return (uint32_t)codec[(sidx * (uint32_t)kSuperFrames + lane) % C]; };
+    auto grab = [&]() { return bq_grab(bq, gqueue, G, lane, 0u); };
+
+    uint32_t sidx = blockIdx.x * (uint32_t)kWaves + wave;
+    if (sidx < n_super) {
+        uint4 d[QP];
+        uint32_t cur_pt = fetch_pt(sidx);
+        {
+            const uint8_t *b0 = payload + (uint64_t)sidx * item_bytes;
+#pragma unroll
+            for (int j = 0; j < QP; ++j) d[j] = ld16_dw(b0 + po_of(j));
+        }
+        uint32_t s_next = grab();
+        for (;;) {
+            const bool has_next = s_next < n_super;
+            const uint32_t s_load = has_next ? s_next : 0u;      // last round: re-read item 0 (L2-hot), loads stay unconditional
+            const uint32_t f0 = sidx * kSuperFrames;
+            const bool my_alaw = cur_pt == IGDSP_PT_PCMA;
+            const uint64_t amask = __ballot(my_alaw);
+            const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
+            const uint8_t *nbase = payload + (uint64_t)s_load * item_bytes;
+            const uint32_t nxt_pt = fetch_pt(s_load);
+#pragma unroll
+            for (int j = 0; j < kPk; ++j) asm volatile("" : "+v"(pk[j]));   // unpack per use: hoisted, the constants would take 3 QP registers
+            {
+                uint2 e[2][8];
+                uint32_t wa[2], wb[2];
+                auto issue = [&](int u) {
+                    const int j = u >> 1, k = u & 1;
+                    wa[k] = (u & 1) ? d[j].z : d[j].x;
+                    wb[k] = (u & 1) ? d[j].w : d[j].y;
+                    const uint32_t frj = fr_of(j);
+                    const uint32_t bit = frj < 32u ? (uint32_t)__builtin_amdgcn_sbfe(am_lo, frj, 1) : (uint32_t)__builtin_amdgcn_sbfe(am_hi, frj - 32u, 1);
+                    const uint32_t lmj = bit & 0x80808080u;
+                    const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lmj, tb = (wb[k] & 0x7F7F7F7Fu) | lmj;
+                    e[k][0] = lut_at(lds, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lds, ta, off, 0x0C0C0500u);
+                    e[k][2] = lut_at(lds, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lds, ta, off, 0x0C0C0700u);
+                    e[k][4] = lut_at(lds, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lds, tb, off, 0x0C0C0500u);
+                    e[k][6] = lut_at(lds, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lds, tb, off, 0x0C0C0700u);
+                };
+                uint32_t sum = 0, peak = 0, bsum = 0;
+                issue(0);
+#pragma unroll
+                for (int u = 0; u < 2 * QP; ++u) {
+                    const int j = u >> 1, k = u & 1;
+                    if (u + 1 < 2 * QP) issue(u + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    bsum = __builtin_amdgcn_sad_u8(wa[k], 0u, bsum);
+                    bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
+                    sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
+                    sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
+                    peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
+                    peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
+                    if (k == 1) {                               // piece j complete
+                        uint2 ent = make_uint2(sum, peak | (bsum << 16) | probe_fail(d[j], 0xFFu << ps_of(j)));
+                        if (tail_of(j)) ent = make_uint2(d[j].z, d[j].w);       // the frame's last two dwords, raw
+                        strip[j * 64 + lane] = ent;
+                        d[j] = ld16_dw(nbase + po_of(j));
+                        sum = 0; peak = 0; bsum = 0;
+                    }
+                }
+            }
+            const uint32_t s_after = has_next ? grab() : 0xFFFFFFFFu;
+            wave_lds_fence();
+            {
+                const uint2 *row = strip + lane * QP;              // the pieces of this lane's frame
+                uint64_t s = 0;
+                uint32_t peak = 0, bsum = 0, fail = 0, part = 0;
+#pragma unroll
+                for (int i = 0; i < Q; ++i) {
+                    const uint2 v = row[i];
+                    part += v.x;                                  // 30-bit piece sums: four fit 32 bits
+                    if ((i & 3) == 3 || i == Q - 1) { s += part; part = 0; }
+                    peak = max(peak, v.y & 0x7FFFu);
+                    bsum += (v.y >> 16) & 0x7FFFu;
+                    fail |= v.y;
+                }
+                if (TAIL) {                                        // the frame's tail dwords (bytes 16 Q .. n - 1), expanded by the frame's own lane
+                    const uint2 tv = row[Q];
+                    const uint32_t lm = my_alaw ? 0x80808080u : 0u;
+                    const uint32_t tws[2] = {T == 2u ? tv.x : tv.y, tv.y};
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        if ((uint32_t)t < T) {
+                            const uint32_t w = tws[t], tt = (w & 0x7F7F7F7Fu) | lm;
+                            const uint2 e0 = lut_at(lds, tt, off, 0x0C0C0400u), e1 = lut_at(lds, tt, off, 0x0C0C0500u);
+                            const uint2 e2 = lut_at(lds, tt, off, 0x0C0C0600u), e3 = lut_at(lds, tt, off, 0x0C0C0700u);
+                            s += (uint64_t)(e0.x + e1.x + e2.x + e3.x);
+                            peak = max(max(peak, e0.y), max(e1.y, max(e2.y, e3.y)));
+                            bsum = __builtin_amdgcn_sad_u8(w, 0u, bsum);
+                        }
+                }
+                const bool probe = (Q >= 4) && (fail >> 31) == 0u;  // bytes 28 / 38 / 48 exist only when n > 48
+                uint32_t bm, fl;
+                st_stream(reinterpret_cast<uint4 *>(stats + (f0 + lane)), pack_stats(s << 4, peak, bsum, n, my_alaw, probe, bm, fl));
+                if (AGG) {
+                    a_sumsq += s << 4; a_bm += bm; a_peak = max(a_peak, peak);
+                    u_frames += (uint32_t)kSuperFrames;
+                    u_sil += (uint32_t)__builtin_popcountll(__ballot((fl & IGDSP_FLAG_SILENT) != 0u));
+                    u_clip += (uint32_t)__builtin_popcountll(__ballot((fl & IGDSP_FLAG_CLIPPED) != 0u));
+                }
+            }
+            wave_lds_fence();
+            if (!has_next) break;
+            sidx = s_next;
+            s_next = s_after;
+            cur_pt = nxt_pt;
+        }
+    }
+    bq_finish(gqueue, G);
+    if (AGG && agg != nullptr) {
+        const bool l0 = lane == 0u;
+        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kWaves, a_sumsq, l0 ? (uint64_t)u_frames * n : 0ull, l0 ? u_frames : 0u,
+                         l0 ? u_sil : 0u, l0 ? u_clip : 0u, a_bm, a_peak);
+    }
+}
+
 // Short payloads in the fused packet kernels.  transport_rtp_cb accepts any payloadlen = size - header
 // (TransportAdapter.cpp:270-291; the hook anticipates 164 and 24, roip_ed137.cpp:6561-6562).  The pipeline above is built
 // for whole 160-byte payloads; a packet with 0 < payloadlen < 160 is rare, so its FRAME LANE re-meters it alone, straight
@@ -2711,6 +2890,27 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
+    // dense frames of the other reference sizes (16 Q + 4 T bytes, Q in {1, 5, 10, 15}, T <= 2) keep the chunk pipeline: k_meter_strided
+    if (done == 0 && variant != 1 && len == nullptr && pcm == nullptr && (n & 3u) == 0u && n != (uint32_t)kFrame && n_frames >= (uint32_t)kSuperFrames &&
+        ((n >> 2) & 3u) != 3u && n >= 16u &&
+        ((reinterpret_cast<uintptr_t>(payload) & 3u) == 0u) && ((reinterpret_cast<uintptr_t>(stats) & 15u) == 0u) && std::getenv("IGDSP_NO_STRIDED") == nullptr) {
+        const uint32_t Qn = n >> 4;
+        const bool tail = (n & 15u) != 0u;
+        const uint32_t n_super = n_frames / kSuperFrames;
+        const uint32_t whole = n_super * kSuperFrames;
+#define IGDSP_STRIDED(QV, TV)                                                                                                                         \
+        if (Qn == QV && tail == TV) {                                                                                                                 \
+            constexpr int w = StridedGeom<QV + (TV ? 1 : 0)>::kWaves;                                                                                 \
+            const uint32_t grid = blocks_for(n_super, w, (uint32_t)cfg.compute_units);                                                                \
+            if (agg) hipLaunchKernelGGL((k_meter_strided<QV, TV, true>), dim3(grid), dim3(w * 64), 0, s, payload, codec, C, whole, n, stats, agg, rank, gq);   \
+            else     hipLaunchKernelGGL((k_meter_strided<QV, TV, false>), dim3(grid), dim3(w * 64), 0, s, payload, codec, C, whole, n, stats, agg, rank, gq);  \
+            done = whole;                                                                                                                             \
+        }
+        IGDSP_STRIDED(1, false) IGDSP_STRIDED(1, true) IGDSP_STRIDED(5, false) IGDSP_STRIDED(5, true)
+        IGDSP_STRIDED(10, true) IGDSP_STRIDED(15, false)       // (15, true) = 244 / 248 bytes would need 16 pieces x 12 waves of strip: image kernel
+#undef IGDSP_STRIDED
+        if (done) { hipError_t e = hipGetLastError(); if (e != hipSuccess) return e; }
+    }
     if (done < n_frames) {
         // what the tuned n == 160 kernel does not take: other frame sizes, ragged lengths, the < 64-frame tail.  Meter-only
         // work with n % 4 == 0 goes through the LDS-image kernel (every lane meters one frame); PCM output, n % 4 != 0 and
@@ -2720,7 +2920,8 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
         if (image_ok) {
             const uint32_t img = (uint32_t)kSuperFrames * n;
             const uint32_t lut_bytes = (uint32_t)kLutEntries * 8u;
-            const uint32_t waves = std::max(1u, std::min(kImgMaxWaves, (160u * 1024u - lut_bytes - 2048u) / img));
+            uint32_t waves = std::max(1u, std::min(kImgMaxWaves, (160u * 1024u - lut_bytes - 2048u) / img));
+            if (const char *e = std::getenv("IGDSP_IMG_WAVES")) waves = std::max(1u, std::min(waves, (uint32_t)std::atoi(e)));   // experiments
             const uint32_t items = (n_frames - done + (uint32_t)kSuperFrames - 1u) / (uint32_t)kSuperFrames;
             const uint32_t grid = blocks_for(items, waves, (uint32_t)cfg.compute_units);
             const size_t smem = (size_t)waves * img;              // dynamic part: the images (the LUT is static)

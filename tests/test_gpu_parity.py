@@ -105,13 +105,15 @@ def test_ragged_lengths_and_odd_frame_sizes(ctx, orc, n):
     gu.assert_stats_equal(st, est, n=n)
 
 
-@pytest.mark.parametrize("n", [4, 24, 80, 164, 240, 256, 160])
+@pytest.mark.parametrize("n", [4, 16, 20, 24, 80, 88, 164, 168, 172, 240, 244, 256, 160])
 @pytest.mark.parametrize("ragged", [False, True])
 def test_other_frame_sizes_image_kernel(ctx, orc, n, ragged):
     """Frame sizes other than 160 (the reference's hook anticipates 164 and 24, roip_ed137.cpp:6561-6562) and ragged frames
-    no longer fall to the wave-per-frame kernel: k_meter_image meters one frame per lane from an LDS image of 64 frames.
-    Whole items, a tail item, channel wrap inside an item, mixed laws, edge frames, the aggregate; every record against the
-    oracle (160 with lengths exercises the same kernel: the tuned path takes dense frames only)."""
+    no longer fall to the wave-per-frame kernel.  Dense frames of 16 Q + 4 T bytes with Q in {1, 5, 10, 15}, T <= 2 (16, 20,
+    24, 80, 88, 164, 168, 240) keep the chunk pipeline at a frame stride (k_meter_strided, with the tail piece handed to the
+    frame lane); every other n % 4 == 0 size, ragged lengths and the < 64-frame tail go through k_meter_image (one frame per
+    lane from an LDS image of 64 frames).  Whole items, a tail item, channel wrap inside an item, mixed laws, edge frames,
+    the aggregate; every record against the oracle."""
     if n == 160 and not ragged:
         pytest.skip("dense 160-byte frames are the tuned kernel's (tested above)")
     C_, F_ = 150, 7                                  # 1050 frames = 16 items + a tail of 26
