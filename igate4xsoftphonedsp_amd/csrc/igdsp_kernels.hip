@@ -2890,7 +2890,8 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    // dense frames of the other reference sizes (16 Q + 4 T bytes, Q in {1, 5, 10, 15}, T <= 2) keep the chunk pipeline: k_meter_strided
+    // dense frames of 16 Q + 4 T bytes, Q in {1, 4, 5, 6, 8, 10, 12, 15}, T <= 2 (the reference's 164 / 24 and the 5 ms multiples
+    // up to 240) keep the chunk pipeline: k_meter_strided
     if (done == 0 && variant != 1 && len == nullptr && pcm == nullptr && (n & 3u) == 0u && n != (uint32_t)kFrame && n_frames >= (uint32_t)kSuperFrames &&
         ((n >> 2) & 3u) != 3u && n >= 16u &&
         ((reinterpret_cast<uintptr_t>(payload) & 3u) == 0u) && ((reinterpret_cast<uintptr_t>(stats) & 15u) == 0u) && std::getenv("IGDSP_NO_STRIDED") == nullptr) {
@@ -2906,8 +2907,9 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
             else     hipLaunchKernelGGL((k_meter_strided<QV, TV, false>), dim3(grid), dim3(w * 64), 0, s, payload, codec, C, whole, n, stats, agg, rank, gq);  \
             done = whole;                                                                                                                             \
         }
-        IGDSP_STRIDED(1, false) IGDSP_STRIDED(1, true) IGDSP_STRIDED(5, false) IGDSP_STRIDED(5, true)
-        IGDSP_STRIDED(10, true) IGDSP_STRIDED(15, false)       // (15, true) = 244 / 248 bytes would need 16 pieces x 12 waves of strip: image kernel
+        IGDSP_STRIDED(1, false) IGDSP_STRIDED(1, true) IGDSP_STRIDED(4, false) IGDSP_STRIDED(4, true) IGDSP_STRIDED(5, false) IGDSP_STRIDED(5, true)
+        IGDSP_STRIDED(6, false) IGDSP_STRIDED(6, true) IGDSP_STRIDED(8, false) IGDSP_STRIDED(8, true) IGDSP_STRIDED(10, true)
+        IGDSP_STRIDED(12, false) IGDSP_STRIDED(12, true) IGDSP_STRIDED(15, false)   // (15, true) = 244 / 248 bytes: 16 pieces x 12 waves of strip do not fit
 #undef IGDSP_STRIDED
         if (done) { hipError_t e = hipGetLastError(); if (e != hipSuccess) return e; }
     }

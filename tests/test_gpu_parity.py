@@ -105,7 +105,7 @@ def test_ragged_lengths_and_odd_frame_sizes(ctx, orc, n):
     gu.assert_stats_equal(st, est, n=n)
 
 
-@pytest.mark.parametrize("n", [4, 16, 20, 24, 80, 88, 164, 168, 172, 240, 244, 256, 160])
+@pytest.mark.parametrize("n", [4, 16, 20, 24, 64, 72, 80, 88, 96, 100, 128, 136, 164, 168, 172, 192, 200, 240, 244, 256, 160])
 @pytest.mark.parametrize("ragged", [False, True])
 def test_other_frame_sizes_image_kernel(ctx, orc, n, ragged):
     """Frame sizes other than 160 (the reference's hook anticipates 164 and 24, roip_ed137.cpp:6561-6562) and ragged frames
