@@ -49,6 +49,15 @@ __device__ __forceinline__ uint4 ld_stream(const uint4 *p)
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// 16 bytes at dword (not 16-byte) alignment: gfx950 global loads only need dword alignment for dwordx4 (measured < 1 %
+// slower than aligned ones in a bare stream, tools/misaligned_loads.py).  Nontemporal like every other streaming load here.
+typedef uint32_t u32x4_a4_t __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ uint4 ld16_dw(const uint8_t *p)
+{
+    const u32x4_a4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4_t *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // write-once 16-byte store (records / PCM are never re-read by this launch)
 #ifndef IGDSP_NT_STORE
 #define IGDSP_NT_STORE 0      // cached stores measured ~1 % faster than nontemporal for the 1 KiB record blocks
@@ -807,7 +816,7 @@ __global__ __launch_bounds__(kImgMaxWaves * 64) void k_meter_image(
     uint32_t first_frame, uint32_t n_frames, uint32_t n, igdsp_frame_stats *__restrict__ stats, igdsp_aggregate *agg, uint32_t rank)
 {
     // frames [first_frame, n_frames) of the batch in items of 64; all pointers are the batch bases; payload + first_frame * n
-    // is 16-byte aligned (launcher)
+    // is dword aligned (launcher)
     __shared__ uint2 lut[kLutEntries];                            // static, at LDS offset 0: LUT addresses need no base add
     extern __shared__ __attribute__((aligned(16))) uint8_t img_smem[];   // the waves' images (sized at launch)
     const uint32_t n_waves = blockDim.x >> 6;
@@ -844,7 +853,7 @@ __global__ __launch_bounds__(kImgMaxWaves * 64) void k_meter_image(
             if ((uint32_t)j < np) {                              // wave-uniform
                 const uint32_t o = ((uint32_t)j * 64u + lane) * 16u;
                 const uint8_t *a = (o + 16u <= avail) ? src + o : payload;
-                d[j] = ld_stream(reinterpret_cast<const uint4 *>(a));
+                d[j] = ld16_dw(a);                                 // dword alignment is enough (n % 4 == 0, dword-aligned batch)
             }
     };
     const uint32_t stride_items = gridDim.x * n_waves;
@@ -980,15 +989,6 @@ constexpr int kSlotPieces = IGDSP_SLOT_BYTES / 16;                 // 12
 constexpr int kRtpHalfLoads = kSlotPieces * kChunkFrames / 64;     // 6 loads per lane per 32-slot half
 constexpr int kRtpStrip = kSuperFrames * kSlotPieces;              // 768 entries = 6 KiB per wave
 constexpr int kRtpWaves = 12;                                      // 64 KiB LUT + 72 KiB strips
-
-// 16 bytes at dword (not 16-byte) alignment: gfx950 global loads only need dword alignment for dwordx4 (measured < 1 %
-// slower than aligned ones in a bare stream, tools/misaligned_loads.py).  Nontemporal like every other streaming load here.
-typedef uint32_t u32x4_a4_t __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ uint4 ld16_dw(const uint8_t *p)
-{
-    const u32x4_a4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4_t *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
 
 // SLOT = true : 192-byte slots (size word + pad + packet at +12), every piece 16-byte aligned.
 // SLOT = false: packets packed at `stride` bytes exactly as received; piece addresses are only dword aligned.
@@ -2892,7 +2892,7 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
     }
     // dense frames of 16 Q + 4 T bytes, Q in {1, 4, 5, 6, 8, 10, 12, 15}, T <= 2 (the reference's 164 / 24 and the 5 ms multiples
     // up to 240) keep the chunk pipeline: k_meter_strided
-    if (done == 0 && variant != 1 && len == nullptr && pcm == nullptr && (n & 3u) == 0u && n != (uint32_t)kFrame && n_frames >= (uint32_t)kSuperFrames &&
+    if (done == 0 && variant != 1 && len == nullptr && pcm == nullptr && (n & 3u) == 0u && n_frames >= (uint32_t)kSuperFrames &&   // (160-byte frames land here only when their buffer is not 16-byte aligned)
         ((n >> 2) & 3u) != 3u && n >= 16u &&
         ((reinterpret_cast<uintptr_t>(payload) & 3u) == 0u) && ((reinterpret_cast<uintptr_t>(stats) & 15u) == 0u) && std::getenv("IGDSP_NO_STRIDED") == nullptr) {
         const uint32_t Qn = n >> 4;
@@ -2908,7 +2908,7 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
             done = whole;                                                                                                                             \
         }
         IGDSP_STRIDED(1, false) IGDSP_STRIDED(1, true) IGDSP_STRIDED(4, false) IGDSP_STRIDED(4, true) IGDSP_STRIDED(5, false) IGDSP_STRIDED(5, true)
-        IGDSP_STRIDED(6, false) IGDSP_STRIDED(6, true) IGDSP_STRIDED(8, false) IGDSP_STRIDED(8, true) IGDSP_STRIDED(10, true)
+        IGDSP_STRIDED(6, false) IGDSP_STRIDED(6, true) IGDSP_STRIDED(8, false) IGDSP_STRIDED(8, true) IGDSP_STRIDED(10, false) IGDSP_STRIDED(10, true)
         IGDSP_STRIDED(12, false) IGDSP_STRIDED(12, true) IGDSP_STRIDED(15, false)   // (15, true) = 244 / 248 bytes: 16 pieces x 12 waves of strip do not fit
 #undef IGDSP_STRIDED
         if (done) { hipError_t e = hipGetLastError(); if (e != hipSuccess) return e; }
@@ -2918,7 +2918,7 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
         // work with n % 4 == 0 goes through the LDS-image kernel (every lane meters one frame); PCM output, n % 4 != 0 and
         // unaligned buffers through the literal wave-per-frame kernel.
         const bool image_ok = variant != 1 && pcm == nullptr && (n & 3u) == 0u && ((reinterpret_cast<uintptr_t>(stats) & 15u) == 0u) &&
-                              (((reinterpret_cast<uintptr_t>(payload) + (uint64_t)done * n) & 15u) == 0u) && n_frames - done >= 16u;
+                              ((reinterpret_cast<uintptr_t>(payload) & 3u) == 0u) && n_frames - done >= 16u;
         if (image_ok) {
             const uint32_t img = (uint32_t)kSuperFrames * n;
             const uint32_t lut_bytes = (uint32_t)kLutEntries * 8u;

@@ -133,6 +133,30 @@ def test_other_frame_sizes_image_kernel(ctx, orc, n, ragged):
     assert agg["peak_slot"].tolist() == eagg["peak_slot"].tolist()
 
 
+@pytest.mark.parametrize("n", [160, 164, 80])
+def test_dword_aligned_payload_keeps_the_chunk_pipeline(ctx, orc, n):
+    """A payload buffer that is only dword aligned (base + 4) cannot take the 16-byte aligned loads of k_meter_chunk64 /
+    k_meter_image; k_meter_strided's dword-aligned loads serve it (160-byte frames included) instead of the wave-per-frame
+    kernel.  Records and aggregate against the oracle."""
+    torch = gu.torch_cuda()
+    C_, F_ = 200, 5
+    payload = orc.gen_uniform(F_ * C_ * n, seed=n + 1).reshape(F_, C_, n)
+    codec = np.where(np.arange(C_) % 3 == 1, 8, 0).astype(np.uint8)
+    raw = gu.dev_zeros(F_ * C_ * n + 64, 0xEE)
+    d_pl = raw[4:4 + F_ * C_ * n]
+    d_pl.copy_(torch.from_numpy(payload.reshape(-1).copy()))
+    assert d_pl.data_ptr() % 16 == 4
+    d_st, d_agg = gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.dev_zeros(capi.AGGREGATE.itemsize)
+    ctx.decode_meter(d_pl, gu.to_dev(codec), C_, F_, n, d_st, agg=d_agg, rank=1)
+    torch.cuda.synchronize()
+    est, eagg = orc.decode_meter(payload, codec, want_agg=True, rank=1)
+    gu.assert_stats_equal(gu.to_host(d_st, capi.FRAME_STATS, (F_, C_)), est, n=n)
+    agg = gu.to_host(d_agg, capi.AGGREGATE)[0]
+    for f in ("sumsq", "samples", "frames", "n_silent", "n_clipped", "byte_mean_sum"):
+        assert int(agg[f]) == int(eagg[f]), f
+    assert np.all(raw[:4].cpu().numpy() == 0xEE) and np.all(raw[4 + F_ * C_ * n:].cpu().numpy() == 0xEE)
+
+
 def test_config1_golden_fixture_through_gpu(ctx, golden_dir):
     """4 ch x 50 frames of the committed fixture: GPU vs values derived from audioop (not our oracle)."""
     g = np.load(os.path.join(golden_dir, "config1_4ch_50f.npz"))
