@@ -346,7 +346,8 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
     };
 
     // Below 512 MiB of inputs a launch works out of the 256 MiB Infinity Cache and placement does not matter.
-    const bool want_place = in_bytes >= ((size_t)512 << 20) && (rec_chunks + bulk_chunks) > 0 && limit / chunk >= 4 * kSrcChunks;
+    // (a set of INPUT buffers only is still worth placing once it is larger than the probe source: all of it lands in ONE class)
+    const bool want_place = in_bytes >= ((size_t)512 << 20) && ((rec_chunks + bulk_chunks) > 0 || in_chunks > kSrcChunks) && limit / chunk >= 4 * kSrcChunks;
     std::vector<size_t> poolA, poolB, poolC;        // chunk indices: class of the inputs / first other class / second other class
     bool ok = true;
     if (want_place) {
@@ -539,7 +540,7 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
     // Hand the picked chunks to their buffers: INPUT buffers from pool A, RECORD buffers and the first halves of the BULK
     // buffers from pool B, the second halves from pool C (from B when there is no third class); a pool that runs dry is topped
     // up from the other output pool, and whatever a buffer still lacks after that comes from fresh consecutive chunks.
-    if (ok && !poolB.empty()) {
+    if (ok && (!poolB.empty() || (rec_chunks + bulk_chunks == 0 && !poolA.empty()))) {
         for (size_t i = 0; i < X.chunks.size(); ++i) X.unmap_scratch(i);
         size_t a = 0, b = 0, c = 0;
         bool all = true;

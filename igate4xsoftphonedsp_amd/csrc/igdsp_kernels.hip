@@ -1096,16 +1096,18 @@ __device__ __forceinline__ void bq_finish(uint32_t *gq, uint32_t G)             
 // lines — 0.48 of peak at n = 164 against 0.80 at n = 240.)  Item = 64 frames = Q + TAIL wave-wide loads, every piece
 // register re-loaded from the next item the moment it is folded; block / device work queue as in k_meter_chunk64.
 // ============================================================================
-template <int QP> struct StridedGeom { static constexpr int kWaves = QP <= 11 ? 16 : 12; };
+// STORE: the decoded int16 PCM goes out as well (pcm[F][C][n], dword aligned): every payload piece stores its 32 bytes as two
+// dword-aligned 16-byte stores, the tail piece the 8 T bytes of the frame's tail samples; 12 waves (eight more live registers).
+template <int QP, bool STORE = false> struct StridedGeom { static constexpr int kWaves = (QP <= 11 && !STORE) ? 16 : 12; };
 
-template <int Q, bool TAIL, bool AGG>
-__global__ __launch_bounds__(StridedGeom<Q + (TAIL ? 1 : 0)>::kWaves * 64) void k_meter_strided(
+template <int Q, bool TAIL, bool AGG, bool STORE = false>
+__global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 64)) void k_meter_strided(
     const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t n_frames, uint32_t n,
-    igdsp_frame_stats *__restrict__ stats, igdsp_aggregate *agg, uint32_t rank, uint32_t *gqueue)
+    igdsp_frame_stats *__restrict__ stats, igdsp_aggregate *agg, uint32_t rank, uint32_t *gqueue, int16_t *__restrict__ pcm = nullptr)
 {
     static_assert(Q == 1 || Q >= 4, "the probe bytes 28 / 38 / 48 are taken from pieces 1 / 2 / 3");
     constexpr int QP = Q + (TAIL ? 1 : 0);                       // pieces per frame
-    constexpr int kWaves = StridedGeom<QP>::kWaves;
+    constexpr int kWaves = StridedGeom<QP, STORE>::kWaves;
     constexpr int kStrip = kSuperFrames * QP;
     __shared__ uint2 lds[kLutEntries + kWaves * kStrip];
     __shared__ BlockQueue<kWaves> bq;
@@ -1186,6 +1188,7 @@ __global__ __launch_bounds__(StridedGeom<Q + (TAIL ? 1 : 0)>::kWaves * 64) void 
                     e[k][6] = lut_at(lds, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lds, tb, off, 0x0C0C0700u);
                 };
                 uint32_t sum = 0, peak = 0, bsum = 0;
+                uint32_t o[8];
                 issue(0);
 #pragma unroll
                 for (int u = 0; u < 2 * QP; ++u) {
@@ -1198,10 +1201,30 @@ __global__ __launch_bounds__(StridedGeom<Q + (TAIL ? 1 : 0)>::kWaves * 64) void 
                     sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
                     peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
                     peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
+                    if (STORE) {
+                        o[4 * k + 0] = pack_pcm(wa[k], 0, e[k][0].y, e[k][1].y); o[4 * k + 1] = pack_pcm(wa[k], 2, e[k][2].y, e[k][3].y);
+                        o[4 * k + 2] = pack_pcm(wb[k], 0, e[k][4].y, e[k][5].y); o[4 * k + 3] = pack_pcm(wb[k], 2, e[k][6].y, e[k][7].y);
+                    }
                     if (k == 1) {                               // piece j complete
                         uint2 ent = make_uint2(sum, peak | (bsum << 16) | probe_fail(d[j], 0xFFu << ps_of(j)));
                         if (tail_of(j)) ent = make_uint2(d[j].z, d[j].w);       // the frame's last two dwords, raw
                         strip[j * 64 + lane] = ent;
+                        if (STORE) {
+                            // 16 samples = 32 bytes at twice the payload offset.  The tail piece's last T dwords are the frame's tail:
+                            // their 8 T bytes of PCM go right behind the 32 bytes of the previous lane (piece Q - 1 of the same
+                            // frame), so the wave's stores stay one contiguous run per frame.
+                            u32x4_a4_t v0, v1;
+                            v0.x = o[0]; v0.y = o[1]; v0.z = o[2]; v0.w = o[3]; v1.x = o[4]; v1.y = o[5]; v1.z = o[6]; v1.w = o[7];
+                            if (!tail_of(j)) {
+                                uint8_t *op = reinterpret_cast<uint8_t *>(pcm) + 2ull * ((uint64_t)sidx * item_bytes + po_of(j));
+                                reinterpret_cast<u32x4_a4_t *>(op)[0] = v0;
+                                reinterpret_cast<u32x4_a4_t *>(op)[1] = v1;
+                            } else {
+                                uint8_t *op = reinterpret_cast<uint8_t *>(pcm) + 2ull * ((uint64_t)sidx * item_bytes + fr_of(j) * n + 16u * Q);
+                                if (T == 2u) reinterpret_cast<u32x4_a4_t *>(op)[0] = v1;
+                                else { reinterpret_cast<uint32_t *>(op)[0] = o[6]; reinterpret_cast<uint32_t *>(op)[1] = o[7]; }
+                            }
+                        }
                         d[j] = ld16_dw(nbase + po_of(j));
                         sum = 0; peak = 0; bsum = 0;
                     }
@@ -2891,26 +2914,36 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
         if (e != hipSuccess) return e;
     }
     // dense frames of 16 Q + 4 T bytes, Q in {1, 4, 5, 6, 8, 10, 12, 15}, T <= 2 (the reference's 164 / 24 and the 5 ms multiples
-    // up to 240) keep the chunk pipeline: k_meter_strided
-    if (done == 0 && variant != 1 && len == nullptr && pcm == nullptr && (n & 3u) == 0u && n_frames >= (uint32_t)kSuperFrames &&   // (160-byte frames land here only when their buffer is not 16-byte aligned)
-        ((n >> 2) & 3u) != 3u && n >= 16u &&
+    // up to 240) keep the chunk pipeline: k_meter_strided.  With PCM output: the reference's own sizes (24, 80, 164 / 168, 240).
+    if (done == 0 && variant != 1 && len == nullptr && (n & 3u) == 0u && n_frames >= (uint32_t)kSuperFrames &&   // (160-byte frames land here only when their buffer is not 16-byte aligned)
+        ((n >> 2) & 3u) != 3u && n >= 16u && ((reinterpret_cast<uintptr_t>(pcm) & 3u) == 0u) &&
         ((reinterpret_cast<uintptr_t>(payload) & 3u) == 0u) && ((reinterpret_cast<uintptr_t>(stats) & 15u) == 0u) && std::getenv("IGDSP_NO_STRIDED") == nullptr) {
         const uint32_t Qn = n >> 4;
         const bool tail = (n & 15u) != 0u;
         const uint32_t n_super = n_frames / kSuperFrames;
         const uint32_t whole = n_super * kSuperFrames;
 #define IGDSP_STRIDED(QV, TV)                                                                                                                         \
-        if (Qn == QV && tail == TV) {                                                                                                                 \
+        if (Qn == QV && tail == TV && pcm == nullptr) {                                                                                               \
             constexpr int w = StridedGeom<QV + (TV ? 1 : 0)>::kWaves;                                                                                 \
             const uint32_t grid = blocks_for(n_super, w, (uint32_t)cfg.compute_units);                                                                \
-            if (agg) hipLaunchKernelGGL((k_meter_strided<QV, TV, true>), dim3(grid), dim3(w * 64), 0, s, payload, codec, C, whole, n, stats, agg, rank, gq);   \
-            else     hipLaunchKernelGGL((k_meter_strided<QV, TV, false>), dim3(grid), dim3(w * 64), 0, s, payload, codec, C, whole, n, stats, agg, rank, gq);  \
+            if (agg) hipLaunchKernelGGL((k_meter_strided<QV, TV, true>), dim3(grid), dim3(w * 64), 0, s, payload, codec, C, whole, n, stats, agg, rank, gq, pcm);   \
+            else     hipLaunchKernelGGL((k_meter_strided<QV, TV, false>), dim3(grid), dim3(w * 64), 0, s, payload, codec, C, whole, n, stats, agg, rank, gq, pcm);  \
+            done = whole;                                                                                                                             \
+        }
+#define IGDSP_STRIDED_PCM(QV, TV)                                                                                                                     \
+        if (Qn == QV && tail == TV && pcm != nullptr) {                                                                                               \
+            constexpr int w = StridedGeom<QV + (TV ? 1 : 0), true>::kWaves;                                                                           \
+            const uint32_t grid = blocks_for(n_super, w, (uint32_t)cfg.compute_units);                                                                \
+            if (agg) hipLaunchKernelGGL((k_meter_strided<QV, TV, true, true>), dim3(grid), dim3(w * 64), 0, s, payload, codec, C, whole, n, stats, agg, rank, gq, pcm);   \
+            else     hipLaunchKernelGGL((k_meter_strided<QV, TV, false, true>), dim3(grid), dim3(w * 64), 0, s, payload, codec, C, whole, n, stats, agg, rank, gq, pcm);  \
             done = whole;                                                                                                                             \
         }
         IGDSP_STRIDED(1, false) IGDSP_STRIDED(1, true) IGDSP_STRIDED(4, false) IGDSP_STRIDED(4, true) IGDSP_STRIDED(5, false) IGDSP_STRIDED(5, true)
         IGDSP_STRIDED(6, false) IGDSP_STRIDED(6, true) IGDSP_STRIDED(8, false) IGDSP_STRIDED(8, true) IGDSP_STRIDED(10, false) IGDSP_STRIDED(10, true)
         IGDSP_STRIDED(12, false) IGDSP_STRIDED(12, true) IGDSP_STRIDED(15, false)   // (15, true) = 244 / 248 bytes: 16 pieces x 12 waves of strip do not fit
+        IGDSP_STRIDED_PCM(1, true) IGDSP_STRIDED_PCM(5, false) IGDSP_STRIDED_PCM(10, true) IGDSP_STRIDED_PCM(10, false) IGDSP_STRIDED_PCM(15, false)
 #undef IGDSP_STRIDED
+#undef IGDSP_STRIDED_PCM
         if (done) { hipError_t e = hipGetLastError(); if (e != hipSuccess) return e; }
     }
     if (done < n_frames) {

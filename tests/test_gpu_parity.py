@@ -157,6 +157,30 @@ def test_dword_aligned_payload_keeps_the_chunk_pipeline(ctx, orc, n):
     assert np.all(raw[:4].cpu().numpy() == 0xEE) and np.all(raw[4 + F_ * C_ * n:].cpu().numpy() == 0xEE)
 
 
+@pytest.mark.parametrize("n", [24, 80, 164, 168, 240, 96])
+def test_decode_with_pcm_at_other_frame_sizes(ctx, orc, n):
+    """Config #2's check (every decoded int16 against the oracle) at the reference's other frame sizes: 24, 80, 164 / 168, 240 keep
+    the chunk pipeline with PCM output (k_meter_strided<STORE>; tail samples stored by the frame lane), 96 falls to the
+    wave-per-frame kernel.  Whole items plus a tail, mixed laws, edge frames, dword-aligned PCM buffer."""
+    torch = gu.torch_cuda()
+    C_, F_ = 170, 5                                   # 850 frames = 13 items + a tail of 18
+    payload = orc.gen_uniform(F_ * C_ * n, seed=3 * n).reshape(F_, C_, n).copy()
+    for k, fr in enumerate(_edge_frames(n)):
+        payload[k % F_, (11 * k) % C_] = fr
+    codec = np.where((np.arange(C_) * 5) % 7 < 3, 8, 0).astype(np.uint8)
+    raw = gu.dev_zeros(F_ * C_ * n * 2 + 64, 0xEE)
+    d_pcm = raw[4:4 + F_ * C_ * n * 2]
+    d_st, d_agg = gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.dev_zeros(capi.AGGREGATE.itemsize)
+    ctx.decode_meter(gu.to_dev(payload), gu.to_dev(codec), C_, F_, n, d_st, pcm=d_pcm, agg=d_agg, rank=2)
+    torch.cuda.synchronize()
+    est, epcm, eagg = orc.decode_meter(payload, codec, want_pcm=True, want_agg=True, rank=2)
+    assert np.array_equal(d_pcm.cpu().numpy().view("<i2").reshape(F_, C_, n), epcm)
+    gu.assert_stats_equal(gu.to_host(d_st, capi.FRAME_STATS, (F_, C_)), est, n=n)
+    agg = gu.to_host(d_agg, capi.AGGREGATE)[0]
+    assert int(agg["sumsq"]) == int(eagg["sumsq"]) and int(agg["frames"]) == C_ * F_
+    assert np.all(raw[:4].cpu().numpy() == 0xEE) and np.all(raw[4 + F_ * C_ * n * 2:].cpu().numpy() == 0xEE)
+
+
 def test_config1_golden_fixture_through_gpu(ctx, golden_dir):
     """4 ch x 50 frames of the committed fixture: GPU vs values derived from audioop (not our oracle)."""
     g = np.load(os.path.join(golden_dir, "config1_4ch_50f.npz"))
@@ -848,22 +872,26 @@ def test_io_alloc_places_buffers_and_they_work(ctx, orc):
         if rep["classes_found"] >= 2:
             assert rep["placed"] == 1 and rep["probe_ms_other"] <= 0.92 * rep["probe_ms_same"]
             # The library's two levels come from its own probe stream on freshly created (zero) memory; with real data the same
-            # stream runs ~4 % slower at either level, so the placed pair is compared with a NAIVE pair on the same data: plain
-            # consecutive allocations through the ABI, as a host following the header literally would make them.
+            # stream runs ~4 % slower at either level, so the placed pair is compared, on the same data, with (i) a pair the
+            # library builds in ONE class on purpose (both buffers given the INPUT role: what consecutive plain allocations
+            # normally amount to) and (ii), for the record, a naive pair of plain consecutive allocations through the ABI.
+            same_set, (s_in, s_st), _ = ctx.io_alloc([(B, capi.IO_INPUT), (F_ * C_ * 16, capi.IO_INPUT)])
             n_in, n_st = ctx.dev_alloc(B), ctx.dev_alloc(F_ * C_ * 16)
             try:
+                ctx.gen_uniform(s_in, B, stream=s)
                 ctx.gen_uniform(n_in, B, stream=s)
                 for _ in range(12):                                                 # clocks, and the driver's clearing of the memory freed above
                     ctx.probe_placement(d_pl, B, out=d_st, reps=10, stream=s)
                 t_placed = min(ctx.probe_placement(d_pl, B, out=d_st, reps=10, stream=s) for _ in range(3))
+                t_same = min(ctx.probe_placement(s_in, B, out=s_st, reps=10, stream=s) for _ in range(3))
                 t_naive = min(ctx.probe_placement(n_in, B, out=n_st, reps=10, stream=s) for _ in range(3))
             finally:
                 ctx.dev_free(n_in)
                 ctx.dev_free(n_st)
-            print(f"bare stream, whole batch -> records: placed {t_placed:.4f} ms, naive {t_naive:.4f} ms, report {rep}")
-            assert t_placed <= 1.03 * t_naive, (t_placed, t_naive)                  # never worse
-            if t_naive > 1.05 * t_placed:                                           # the naive pair shares one class (the usual case):
-                assert t_placed <= 0.94 * t_naive, (t_placed, t_naive, rep)         # measured 7.5-9 % (0.234 vs 0.255 ms); 13-20 % for bulk outputs
+                same_set.close()
+            print(f"bare stream, whole batch -> records: placed {t_placed:.4f} ms, one class on purpose {t_same:.4f} ms, naive {t_naive:.4f} ms, report {rep}")
+            assert t_placed <= 1.03 * t_naive, (t_placed, t_naive)                  # never worse than what a host would get by itself
+            assert t_placed <= 0.95 * t_same, (t_placed, t_same, rep)               # measured 7-9 % (0.234 vs 0.252-0.255 ms); 13-20 % for bulk outputs
     finally:
         ioset.close()
     # small inputs: nothing to place, nothing probed
