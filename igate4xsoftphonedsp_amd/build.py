@@ -41,24 +41,23 @@ def _stale(target: str, sources: list[str]) -> bool:
 def build(force: bool = False, save_asm: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in DEVICE_SOURCES]
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    if force or save_asm or _stale(LIB, deps):
-        cmd = [
-            _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-            "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-result",
-            "-o", LIB, *srcs,
-        ]
-        extra = os.environ.get("IGDSP_CXXFLAGS", "").split()      # A/B experiments: -DIGDSP_...=N
-        cmd[1:1] = extra
+    cmd = [
+        _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-result",
+        "-o", LIB, *srcs,
+    ]
+    cmd[1:1] = os.environ.get("IGDSP_CXXFLAGS", "").split()       # A/B experiments: -DIGDSP_...=N
+    if force or _stale(LIB, deps):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True, cwd=PKG)
-        if save_asm:   # second pass next to a throw-away output: keeps the .s / resource remarks under _asm/
-            asm_dir = os.path.join(PKG, "_asm")
-            os.makedirs(asm_dir, exist_ok=True)
-            acmd = list(cmd)
-            acmd[acmd.index("-o") + 1] = os.path.join(asm_dir, "libigdsp_asm.so")
-            acmd[1:1] = ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
-            subprocess.run(acmd, check=True, cwd=asm_dir)
+    if save_asm:   # a pass of its own next to a throw-away output: keeps the .s / resource remarks under _asm/
+        asm_dir = os.path.join(PKG, "_asm")
+        os.makedirs(asm_dir, exist_ok=True)
+        acmd = list(cmd)
+        acmd[acmd.index("-o") + 1] = os.path.join(asm_dir, "libigdsp_asm.so")
+        acmd[1:1] = ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+        subprocess.run(acmd, check=True, cwd=asm_dir, stderr=subprocess.DEVNULL if not verbose else None)
     host_srcs = [os.path.join(PKG, "host", s) for s in HOST_SOURCES]
     if all(os.path.exists(s) for s in host_srcs):
         hdeps = host_srcs + [os.path.join(PKG, "host", "igdsp_host.h"), os.path.join(INCLUDE, "igdsp.h")]
