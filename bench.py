@@ -164,7 +164,7 @@ def main():
         args.channels = args.total_channels // world
     C_, F_, n = args.channels, args.frames, N_SAMPLES
     if args.frame_bytes != N_SAMPLES:
-        if args.mode not in ("meter", "store") or args.frame_bytes < 4 or args.frame_bytes > 256 or args.frame_bytes % 4:
+        if args.mode not in ("meter", "store", "roundtrip") or args.frame_bytes < 4 or args.frame_bytes > 256 or args.frame_bytes % 4:
             raise SystemExit("--frame-bytes: meter mode only, a multiple of 4 in 4..256")
         n = args.frame_bytes
     C_total = C_ * world
@@ -396,9 +396,9 @@ def main():
     samples_per_step_rank = C_ * F_ * n
     total_samples = samples_per_step_rank * world * args.steps
     value = total_samples / dt / 1e6
-    bps = BYTES_PER_SAMPLE[args.mode] if n == N_SAMPLES else (n + 1 + 16 + (2 * n if args.mode == "store" else 0)) / n
+    bps = BYTES_PER_SAMPLE[args.mode] if n == N_SAMPLES else (n + 1 + 16 + {"store": 2 * n, "roundtrip": n}.get(args.mode, 0)) / n
     achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9
-    kernel_name = "k_encode_lut16" if args.mode == "encode" else "k_wav_expand16" if args.mode == "wav" else "k_meter_rtp64" if args.mode in ("rtp", "packets") else "k_depayload64" if args.mode == "depayload" else ("k_roundtrip_chunk64" if args.variant == 4 else "k_roundtrip_lut64") if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64" if n == N_SAMPLES else "k_meter_strided" if ((n >> 4) in (1, 4, 5, 6, 8, 10, 12, 15) and (n >> 2) & 3 != 3 and n not in (244, 248)) else "k_meter_image")
+    kernel_name = "k_encode_lut16" if args.mode == "encode" else "k_wav_expand16" if args.mode == "wav" else "k_meter_rtp64" if args.mode in ("rtp", "packets") else "k_depayload64" if args.mode == "depayload" else ("k_roundtrip_chunk64" if args.variant == 4 else "k_roundtrip_lut64" if n == N_SAMPLES else "k_roundtrip_strided") if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64" if n == N_SAMPLES else "k_meter_strided" if ((n >> 4) in (1, 4, 5, 6, 8, 10, 12, 15) and (n >> 2) & 3 != 3 and n not in (244, 248)) else "k_meter_image")
 
     out = {
         "metric": "Msamples/s G.711 decode+RMS, 65536ch@8kHz; %HBM roofline at 1/2/4/8 GPU",

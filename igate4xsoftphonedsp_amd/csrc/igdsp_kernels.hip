@@ -2202,6 +2202,186 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_lut64(
 }
 
 // ============================================================================
+// Config #5 at the reference's other frame sizes — k_roundtrip_strided<Q, TAIL>: k_roundtrip_lut64's channel-group-major walk
+// (hold window in registers, frame segments, atomic merge) over frames of n = 16 Q + 4 T bytes with k_meter_strided's piece
+// geometry: Q + TAIL pieces per frame fetched at dword alignment through buffer instructions, the tail piece handing the
+// frame's last dwords raw to the frame lane (stats) and storing their re-encoded bytes itself (output).
+// ============================================================================
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int Q, bool TAIL, int VARIANT>
+__global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
+    const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F, uint32_t n,
+    uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats, igdsp_chan_hold *__restrict__ hold,
+    const uint8_t *__restrict__ gate, uint32_t n_seg, uint32_t n_groups)
+{
+    static_assert(Q == 1 || Q >= 4, "the probe bytes 28 / 38 / 48 are taken from pieces 1 / 2 / 3");
+    constexpr int QP = Q + (TAIL ? 1 : 0);
+    constexpr int kStrip = kSuperFrames * QP;
+    __shared__ uint2 lds[kLutEntries + kRtlWaves * kStrip];
+    fill_recode_lut<VARIANT>(lds);
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint2 *strip = lds + kLutEntries + wave * kStrip;
+    const uint32_t off = (lane & 31u) * 8u;
+    const uint32_t T = (n - 16u * Q) >> 2;
+    constexpr int kPk = (QP + 1) / 2;
+    uint32_t pk[kPk];
+#pragma unroll
+    for (int j = 0; j < kPk; ++j) pk[j] = 0;
+#pragma unroll
+    for (int j = 0; j < QP; ++j) {
+        const uint32_t p = (uint32_t)j * 64u + lane, f = p / (uint32_t)QP, q = p - f * (uint32_t)QP;
+        const uint32_t sh = q == 1u ? 0u : (q == 3u ? 8u : (q == 2u ? 16u : 24u));
+        pk[j >> 1] |= (f | (((TAIL && q == (uint32_t)Q) ? 24u : sh) << 8) | ((TAIL && q == (uint32_t)Q) ? 0x2000u : 0u)) << (16 * (j & 1));
+    }
+    auto fr_of = [&](int j) { return __builtin_amdgcn_ubfe(pk[j >> 1], 16 * (j & 1), 6); };
+    auto ps_of = [&](int j) { return __builtin_amdgcn_ubfe(pk[j >> 1], 16 * (j & 1) + 8, 5); };
+    auto tail_of = [&](int j) { return TAIL && ((pk[j >> 1] >> (16 * (j & 1) + 13)) & 1u) != 0u; };
+    auto po_of = [&](int j) {                                    // byte offset of this lane's piece j inside a 64-channel frame row
+        const uint32_t f = fr_of(j), q = (uint32_t)j * 64u + lane - f * (uint32_t)QP;
+        return f * n + (tail_of(j) ? n - 16u : 16u * q);
+    };
+    const uint32_t total_waves = gridDim.x * kRtlWaves;
+    const uint64_t fbytes = (uint64_t)C * n;                       // bytes between two frames of one channel group
+
+    for (uint32_t item = wave * gridDim.x + blockIdx.x; item < n_groups * n_seg; item += total_waves) {
+        const uint32_t seg = item / n_groups, cg = item - seg * n_groups;
+        const uint32_t f_lo = (uint32_t)(((uint64_t)F * seg) / n_seg), f_hi = (uint32_t)(((uint64_t)F * (seg + 1u)) / n_seg);
+        if (f_lo >= f_hi) continue;
+        const uint32_t c0 = cg * kSuperFrames, cme = c0 + lane;
+        const bool my_alaw = codec[cme] == IGDSP_PT_PCMA;
+        const bool open = (gate == nullptr) || (gate[cme] != 0);
+        uint64_t h_sumsq = 0;
+        uint32_t h_pm = 0, h_min = 255u, h_sc = 0, h_lsum = 0;
+        const uint64_t amask = __ballot(my_alaw);
+        const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
+        const uint8_t *in0 = payload + (uint64_t)c0 * n;
+        uint8_t *out0 = out + (uint64_t)c0 * n;
+
+        uint4 d[QP];
+        {
+            const __amdgpu_buffer_rsrc_t r0 = make_rsrc(in0 + (uint64_t)f_lo * fbytes);
+#pragma unroll
+            for (int j = 0; j < QP; ++j) d[j] = buf_ld_stream(r0, po_of(j), 0u);
+        }
+        for (uint32_t f = f_lo; f < f_hi; ++f) {
+            const bool more = f + 1u < f_hi;
+            const __amdgpu_buffer_rsrc_t rin = make_rsrc(in0 + (uint64_t)(more ? f + 1u : f) * fbytes);
+            const __amdgpu_buffer_rsrc_t rout = make_rsrc(out0 + (uint64_t)f * fbytes);
+#pragma unroll
+            for (int j = 0; j < kPk; ++j) asm volatile("" : "+v"(pk[j]));
+            {
+                uint2 e[2][8];
+                uint32_t wa[2], wb[2];
+                auto issue = [&](int u) {
+                    const int j = u >> 1, k = u & 1;
+                    wa[k] = (u & 1) ? d[j].z : d[j].x;
+                    wb[k] = (u & 1) ? d[j].w : d[j].y;
+                    const uint32_t frj = fr_of(j);
+                    const uint32_t bit = frj < 32u ? (uint32_t)__builtin_amdgcn_sbfe(am_lo, frj, 1) : (uint32_t)__builtin_amdgcn_sbfe(am_hi, frj - 32u, 1);
+                    const uint32_t lmj = bit & 0x80808080u;
+                    const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lmj, tb = (wb[k] & 0x7F7F7F7Fu) | lmj;
+                    e[k][0] = lut_at(lds, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lds, ta, off, 0x0C0C0500u);
+                    e[k][2] = lut_at(lds, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lds, ta, off, 0x0C0C0700u);
+                    e[k][4] = lut_at(lds, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lds, tb, off, 0x0C0C0500u);
+                    e[k][6] = lut_at(lds, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lds, tb, off, 0x0C0C0700u);
+                };
+                auto recode4 = [&](uint32_t w, const uint2 &e0, const uint2 &e1, const uint2 &e2, const uint2 &e3) {
+                    const uint32_t p01 = __builtin_amdgcn_perm(e1.y, e0.y, 0x05040100u);
+                    const uint32_t p23 = __builtin_amdgcn_perm(e3.y, e2.y, 0x05040100u);
+                    const uint32_t sel = ((w >> 7) & 0x01010101u) | 0x06040200u;
+                    return __builtin_amdgcn_perm(p23, p01, sel);
+                };
+                uint32_t sum = 0, peak = 0, bsum = 0;
+                uint32_t o[4];
+                issue(0);
+#pragma unroll
+                for (int u = 0; u < 2 * QP; ++u) {
+                    const int j = u >> 1, k = u & 1;
+                    if (u + 1 < 2 * QP) issue(u + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    bsum = __builtin_amdgcn_sad_u8(wa[k], 0u, bsum);
+                    bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
+                    sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
+                    sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
+                    peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
+                    peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
+                    o[2 * k] = recode4(wa[k], e[k][0], e[k][1], e[k][2], e[k][3]);
+                    o[2 * k + 1] = recode4(wb[k], e[k][4], e[k][5], e[k][6], e[k][7]);
+                    if (k == 1) {
+                        uint2 ent = make_uint2(sum, (peak >> 16) | (bsum << 16) | probe_fail(d[j], 0xFFu << ps_of(j)));
+                        const uint32_t pj = po_of(j);
+                        if (tail_of(j)) {
+                            ent = make_uint2(d[j].z, d[j].w);                   // the frame's last two dwords, raw, for the frame lane
+                            const uint32_t to = fr_of(j) * n + 16u * Q;         // the tail's re-encoded bytes go right behind piece Q - 1
+                            if (T == 2u) { u32x2_t v; v.x = o[2]; v.y = o[3]; __builtin_amdgcn_raw_buffer_store_b64(v, rout, (int)to, 0, 0); }
+                            else __builtin_amdgcn_raw_buffer_store_b32(o[3], rout, (int)to, 0, 0);
+                        } else buf_st(rout, pj, 0u, make_uint4(o[0], o[1], o[2], o[3]));
+                        strip[j * 64 + lane] = ent;
+                        d[j] = buf_ld_stream(rin, pj, 0u);
+                        sum = 0; peak = 0; bsum = 0;
+                    }
+                }
+            }
+            wave_lds_fence();
+            {
+                const uint2 *row = strip + lane * QP;
+                uint64_t sq = 0;
+                uint32_t peak = 0, bsum = 0, fail = 0, part = 0;
+#pragma unroll
+                for (int i = 0; i < Q; ++i) {
+                    const uint2 v = row[i];
+                    part += v.x;
+                    if ((i & 3) == 3 || i == Q - 1) { sq += part; part = 0; }
+                    peak = max(peak, v.y & 0x7FFFu);
+                    bsum += (v.y >> 16) & 0x7FFFu;
+                    fail |= v.y;
+                }
+                if (TAIL) {
+                    const uint2 tv = row[Q];
+                    const uint32_t lm = my_alaw ? 0x80808080u : 0u;
+                    const uint32_t tws[2] = {T == 2u ? tv.x : tv.y, tv.y};
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        if ((uint32_t)t < T) {
+                            const uint32_t w = tws[t], tt = (w & 0x7F7F7F7Fu) | lm;
+                            const uint2 e0 = lut_at(lds, tt, off, 0x0C0C0400u), e1 = lut_at(lds, tt, off, 0x0C0C0500u);
+                            const uint2 e2 = lut_at(lds, tt, off, 0x0C0C0600u), e3 = lut_at(lds, tt, off, 0x0C0C0700u);
+                            sq += (uint64_t)(e0.x + e1.x + e2.x + e3.x);
+                            peak = max(peak, max(max(e0.y, e1.y), max(e2.y, e3.y)) >> 16);
+                            bsum = __builtin_amdgcn_sad_u8(w, 0u, bsum);
+                        }
+                }
+                uint32_t bm, fl;
+                const uint4 rec = pack_stats(sq << 4, peak, bsum, n, my_alaw, (Q >= 4) && (fail >> 31) == 0u, bm, fl);
+                buf_st(make_rsrc(stats + ((uint64_t)f * C + c0)), lane * 16u, 0u, rec);
+                h_sumsq += sq << 4; h_lsum += bm;
+                h_pm = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16_t, h_pm), __builtin_bit_cast(v2u16_t, peak | (bm << 16))));
+                h_min = min(h_min, bm);
+                h_sc += ((fl & IGDSP_FLAG_SILENT) ? 1u : 0u) + ((fl & IGDSP_FLAG_CLIPPED) ? 0x10000u : 0u);
+            }
+            wave_lds_fence();
+        }
+        if (open) {
+            igdsp_chan_hold h;
+            const uint32_t cnt = f_hi - f_lo;
+            h.sumsq_acc = h_sumsq; h.count = cnt; h.level_sum = h_lsum; h.samples = cnt * n;
+            h.peak_hold = (uint16_t)(h_pm & 0xFFFFu); h.level_max = (uint8_t)(h_pm >> 16); h.level_min = (uint8_t)h_min;
+            h.n_silent = h_sc & 0xFFFFu; h.n_clipped = h_sc >> 16;
+            if (n_seg == 1u) {
+                igdsp_chan_hold g = hold[cme];
+                g.sumsq_acc += h.sumsq_acc; g.count += h.count; g.level_sum += h.level_sum; g.samples += h.samples;
+                g.peak_hold = max(g.peak_hold, h.peak_hold); g.level_max = max(g.level_max, h.level_max); g.level_min = min(g.level_min, h.level_min);
+                g.n_silent += h.n_silent; g.n_clipped += h.n_clipped;
+                hold[cme] = g;
+            } else hold_merge(hold + cme, h);
+        }
+    }
+}
+
+// ============================================================================
 // Config #5 for every other shape — k_roundtrip_general: one wavefront per CHANNEL walks that channel's F frames
 // (any n in 1..256, any C, unaligned buffers), lane l owning bytes [4l, 4l + 4) of a frame as in
 // k_meter_wave_per_frame.  Decode through the signed 256-entry LUT, stats by wave reduction, re-encode with the full
@@ -3071,6 +3251,36 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
     // k_roundtrip_general on the same stream.  kernel_variant 4 selects the compressor-cell-table form of the fused
     // kernel (k_roundtrip_chunk64, kept for A/B runs); the default folds the compressor into the expansion LUT.
     const bool aligned = ((reinterpret_cast<uintptr_t>(payload) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(stats)) & 15u) == 0u;
+    // the reference's other frame sizes (24, 80, 164 / 168, 240; dword-aligned buffers suffice) keep the fused walk: k_roundtrip_strided
+    const uint32_t Qn = n >> 4, Tn = (n >> 2) & 3u;
+    const bool strided = kernel_variant != 1 && n != (uint32_t)kFrame && (n & 3u) == 0u && Tn != 3u && n >= 16u &&
+                         (((reinterpret_cast<uintptr_t>(payload) | reinterpret_cast<uintptr_t>(out)) & 3u) == 0u) && ((reinterpret_cast<uintptr_t>(stats) & 15u) == 0u) &&
+                         ((Qn == 1u && Tn != 0u) || (Qn == 5u && Tn == 0u) || (Qn == 10u && Tn != 0u) || (Qn == 15u && Tn == 0u));
+    if (strided && C >= (uint32_t)kSuperFrames) {
+        const uint32_t n_groups_s = C / kSuperFrames;
+        const uint32_t want = (uint32_t)cfg.compute_units * (uint32_t)kRtlWaves;
+        uint32_t n_seg = n_groups_s >= want ? 1u : (want + n_groups_s - 1u) / n_groups_s;
+        n_seg = std::max(1u, std::min(n_seg, std::max(1u, F / 8u)));
+        n_seg = std::max(n_seg, F / 65535u + 1u);
+        const uint32_t grid = blocks_for((uint64_t)n_groups_s * n_seg, kRtlWaves, (uint32_t)cfg.compute_units);
+        const dim3 g3(grid), b3(kRtlWaves * 64);
+#define IGDSP_RTS(QV, TV)                                                                                                                                      \
+        if (Qn == QV && (Tn != 0u) == TV) {                                                                                                                     \
+            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_G191>), g3, b3, 0, s, payload, codec, C, F, n, out, stats, hold, gate, n_seg, n_groups_s);  \
+            else                           hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_SUN16>), g3, b3, 0, s, payload, codec, C, F, n, out, stats, hold, gate, n_seg, n_groups_s); \
+        }
+        IGDSP_RTS(1, true) IGDSP_RTS(5, false) IGDSP_RTS(10, true) IGDSP_RTS(15, false)
+#undef IGDSP_RTS
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const uint32_t c_first = n_groups_s * (uint32_t)kSuperFrames, c_count = C - c_first;
+        if (c_count != 0u) {
+            const uint32_t gridg = blocks_for(c_count, 4, (uint32_t)cfg.compute_units * 8u);
+            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_general<IGDSP_ENC_G191>), dim3(gridg), dim3(256), 0, s, payload, codec, C, F, n, c_first, c_count, out, stats, hold, gate);
+            else                           hipLaunchKernelGGL((k_roundtrip_general<IGDSP_ENC_SUN16>), dim3(gridg), dim3(256), 0, s, payload, codec, C, F, n, c_first, c_count, out, stats, hold, gate);
+        }
+        return hipGetLastError();
+    }
     const uint32_t n_groups = (n == (uint32_t)kFrame && aligned && kernel_variant != 1) ? C / kSuperFrames : 0u;
     if (n_groups != 0u) {
         // fill the chip: at least one work item per resident wave; a segment is never shorter than 8 frames

@@ -346,7 +346,8 @@ def test_roundtrip_peakhold_vs_oracle(ctx, orc, variant, F_):
 
 @pytest.mark.parametrize("kernel", [0, 4])            # 0: compressor folded into the expansion LUT (default); 4: compressor cell table
 @pytest.mark.parametrize("C_,F_,n", [(4, 50, 160), (33, 5, 160), (64, 9, 160), (100, 7, 160), (200, 3, 164), (7, 4, 24), (65, 2, 255),
-                                     (130, 70, 160), (1, 1, 1), (3, 2, 159), (700, 2, 160)])
+                                     (130, 70, 160), (1, 1, 1), (3, 2, 159), (700, 2, 160), (130, 70, 164), (128, 9, 240), (64, 12, 24),
+                                     (192, 33, 80), (65, 10, 168), (256, 5, 20), (128, 4, 172), (128, 4, 96)])
 def test_roundtrip_every_shape_vs_oracle(ctx, orc, kernel, C_, F_, n):
     """igdsp_roundtrip_peakhold serves every geometry: whole groups of 64 channels of 160-byte frames through the fused
     kernel, the C % 64 left-over channels and every other n (164, 24, ... roip_ed137.cpp:6561-6562) / BASELINE config #1's
