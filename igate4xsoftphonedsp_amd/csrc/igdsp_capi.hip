@@ -189,7 +189,7 @@ int igdsp_on_rtp_frame(igdsp_ctx *ctx, int32_t call_id, uint8_t pt, const uint8_
         ctx->frames_dropped[ch] += 1;
         rc = IGDSP_EBUSY;
     }
-    const size_t slot = (size_t)ch * kStageDepth + (ctx->head[ch] % kStageDepth);
+    const size_t slot = (size_t)(ctx->head[ch] % kStageDepth) * ctx->max_channels + ch;   // slot-major: the flush walks each slot plane sequentially
     std::memcpy(ctx->h_ring + slot * kSlot, payload, payloadlen);
     ctx->h_rlen[slot] = (uint16_t)payloadlen;
     ctx->h_rpt[slot] = pt;
@@ -220,7 +220,7 @@ int igdsp_flush(igdsp_ctx *ctx, uint32_t *n_frames_out)
         const uint32_t t0 = ctx->tail[c], h0 = ctx->head[c];
         uint32_t a0 = nA, b0 = nB, newest = kNone;
         for (uint32_t k = t0; k != h0; ++k) {
-            const size_t slot = (size_t)c * kStageDepth + (k % kStageDepth);
+            const size_t slot = (size_t)(k % kStageDepth) * ctx->max_channels + c;
             const uint16_t l = ctx->h_rlen[slot];
             if (l == IGDSP_SAMPLES_PER_FRAME) {
                 std::memcpy(up + L.payA + (size_t)nA * IGDSP_SAMPLES_PER_FRAME, ctx->h_ring + slot * kSlot, l);

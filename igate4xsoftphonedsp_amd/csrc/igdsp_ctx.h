@@ -31,7 +31,8 @@ struct igdsp_ctx {
     std::unordered_map<int32_t, uint32_t> far;
     std::mutex far_mu;
 
-    // staging (host pinned): a ring of kStageDepth frames per channel, ring[c][slot][256] + rlen / rpt per slot; head counts frames
+    // staging (host pinned): a ring of kStageDepth frames per channel, ring[slot][c][256] + rlen / rpt per slot (slot-major: the
+    // frames all calls staged at the same tick position sit next to each other, so the flush reads sequentially); head counts frames
     // written, tail frames taken by igdsp_flush (head - tail <= kStageDepth).  tp_adapter::payload_buff[256] semantics per slot
     // (TransportAdapter.h:66): the reference's hook runs on EVERY frame (TransportAdapter.cpp:303), so every frame is kept.
     uint8_t *h_ring = nullptr;
