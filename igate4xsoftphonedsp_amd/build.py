@@ -19,9 +19,9 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libigdsp.so")
 HOST_LIB = os.path.join(PKG, "libigdsp_host.so")
 
-DEVICE_SOURCES = ["igdsp_kernels.hip", "igdsp_capi.hip", "igdsp_io.hip"]
+DEVICE_SOURCES = ["igdsp_k_meter.hip", "igdsp_k_packets.hip", "igdsp_k_codec.hip", "igdsp_k_misc.hip", "igdsp_capi.hip", "igdsp_io.hip"]
 HOST_SOURCES = ["igdsp_host.cpp"]          # C++ mirror of the reference's adapter/hook interface
-HEADERS = ["igdsp_internal.h", "igdsp_ctx.h", os.path.join(INCLUDE, "igdsp.h")]
+HEADERS = ["igdsp_internal.h", "igdsp_device.h", "igdsp_ctx.h", os.path.join(INCLUDE, "igdsp.h")]
 
 
 def _hipcc() -> str:
@@ -38,26 +38,41 @@ def _stale(target: str, sources: list[str]) -> bool:
     return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
 
 
+def _compile_all(objdir: str, extra: list[str], verbose: bool, cwd: str) -> list[str]:
+    """hipcc -c every device source into objdir, four at a time (the translation units are independent), and return the objects."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    os.makedirs(objdir, exist_ok=True)
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-result"]
+    base[1:1] = os.environ.get("IGDSP_CXXFLAGS", "").split()      # A/B experiments: -DIGDSP_...=N
+    jobs = []
+    for src in DEVICE_SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        jobs.append((base + extra + ["-c", os.path.join(CSRC, src), "-o", obj], obj))
+
+    def run(job):
+        cmd, obj = job
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=cwd, stderr=None if verbose or not extra else subprocess.DEVNULL)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as ex:
+        return list(ex.map(run, jobs))
+
+
 def build(force: bool = False, save_asm: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in DEVICE_SOURCES]
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    cmd = [
-        _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-        "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-result",
-        "-o", LIB, *srcs,
-    ]
-    cmd[1:1] = os.environ.get("IGDSP_CXXFLAGS", "").split()       # A/B experiments: -DIGDSP_...=N
     if force or _stale(LIB, deps):
+        objs = _compile_all(os.path.join(PKG, "_obj"), [], verbose, PKG)
+        link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True, cwd=PKG)
-    if save_asm:   # a pass of its own next to a throw-away output: keeps the .s / resource remarks under _asm/
+            print(" ".join(link))
+        subprocess.run(link, check=True, cwd=PKG)
+    if save_asm:   # a pass of its own: keeps every translation unit's .s (and the resource remarks) under _asm/
         asm_dir = os.path.join(PKG, "_asm")
-        os.makedirs(asm_dir, exist_ok=True)
-        acmd = list(cmd)
-        acmd[acmd.index("-o") + 1] = os.path.join(asm_dir, "libigdsp_asm.so")
-        acmd[1:1] = ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
-        subprocess.run(acmd, check=True, cwd=asm_dir, stderr=subprocess.DEVNULL if not verbose else None)
+        _compile_all(asm_dir, ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"], verbose, asm_dir)
     host_srcs = [os.path.join(PKG, "host", s) for s in HOST_SOURCES]
     if all(os.path.exists(s) for s in host_srcs):
         hdeps = host_srcs + [os.path.join(PKG, "host", "igdsp_host.h"), os.path.join(INCLUDE, "igdsp.h")]

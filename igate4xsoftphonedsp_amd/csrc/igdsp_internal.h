@@ -1,4 +1,4 @@
-// Internal launcher declarations shared by igdsp_kernels.hip and igdsp_capi.hip.
+// Internal launcher declarations shared by the kernel translation units (igdsp_k_*.hip) and igdsp_capi.hip / igdsp_io.hip.
 // Not part of the ABI (include/igdsp.h is).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -14,7 +14,7 @@
 //   * buffers are virtual address ranges (hipMemAddressReserve) onto which chunks of the wanted class are mapped:
 //     INPUT buffers first (their class is "A" by definition), RECORD buffers from chunks of another class, BULK buffers
 //     with their first half from one non-A class and their second half from the other (the queue-driven kernels visit the
-//     two halves of a bulk output alternately, spread_batch in igdsp_kernels.hip);
+//     two halves of a bulk output alternately, spread_batch in igdsp_device.h);
 //   * exploration is sparse (every 16th chunk is probed until a new class shows up, then its neighbours) and bounded by
 //     `explore_limit_bytes`; everything not mapped is released before returning.
 //

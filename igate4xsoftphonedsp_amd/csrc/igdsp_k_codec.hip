@@ -1,0 +1,1174 @@
+// igdsp_k_codec.hip — G.711 compression (k_encode_*), the fused round trip (k_roundtrip_*), the hold / window kernels.
+// Hand-written gfx950 (CDNA4, wave64) kernels; no MFMA: the path is a byte stream with ~4 integer ops per sample, bounded by
+// HBM.  Shared device code: igdsp_device.h.
+#include "igdsp_device.h"
+
+namespace igdsp {
+
+// ============================================================================
+// a2 — G.711 compression.  ONE branch-free formulation serves both laws and both encoder lineages
+// (include/igdsp.h): per-law constants select bias / rounding, the segment comes from count-leading-
+// zeros.  With msb = 31 - clz(mag):
+//   SUN16  mu : mag = min(|v| + 0x84, 0x7FFF)                 A : mag = v >= 0 ? v : max(-v - 8, 0)
+//          seg = max(msb,7) - 7        step = (mag >> (max(msb, mu?7:8) - 4)) & 15
+//   G191   mu : mag = min(|v>>2| + 0x21, 0x1FFF)              A : mag = (v>>3) ^ sign   (= -x-1 for x < 0)
+//          seg = max(msb, mu?5:4) - (mu?5:4)   step = (mag >> (max(msb,5) - 4)) & 15
+//   code = (seg<<4 | step) ^ (mu ? 0xFF : 0xD5) ^ (v < 0 ? 0x80 : 0)
+// (clamping mag is identical to the classic "segment 8 -> 0x7F ^ mask" overflow rule).
+// ============================================================================
+struct EncK { int k_and, k_add, sh; uint32_t c_shift, c_seg, base; };
+
+template <int VARIANT>
+__device__ __forceinline__ EncK enc_consts(bool alaw)
+{
+    EncK k;
+    if (VARIANT == IGDSP_ENC_SUN16) {
+        k.k_and = alaw ? -8 : 0; k.k_add = alaw ? 0 : 0x84; k.sh = 0;
+        k.c_shift = alaw ? 23u : 24u;      // 31 - floor(msb) for the step shift
+        k.c_seg = 24u;                     // 31 - 7
+    } else {
+        k.k_and = alaw ? 0 : 1; k.k_add = alaw ? 0 : 0x21; k.sh = alaw ? 3 : 2;
+        k.c_shift = 26u;                   // 31 - 5
+        k.c_seg = alaw ? 27u : 26u;        // 31 - {4,5}
+    }
+    k.base = alaw ? 0xD5u : 0xFFu;
+    return k;
+}
+
+template <int VARIANT>
+__device__ __forceinline__ uint32_t enc_uni(int v, const EncK k)
+{
+    int mag;
+    const int sign = v >> 31;                                   // -1 for negative samples
+    if (VARIANT == IGDSP_ENC_SUN16) {
+        const int av = (v ^ sign) - sign;                       // |v|, 32768 for -32768
+        mag = min(max(av + ((sign & k.k_and) + k.k_add), 0), 0x7FFF);
+    } else {
+        const int vd = v >> k.sh;                               // arithmetic: floors negatives
+        const int t = vd ^ sign;                                // x >= 0 ? x : -x - 1
+        mag = min(t + (sign & k.k_and) + k.k_add, 0x1FFF);      // mu: |x| + 0x21 ; A: -x - 1
+    }
+    const uint32_t c = (uint32_t)__clz(mag);                    // 32 for mag == 0
+    const uint32_t shift = 27u - min(c, k.c_shift);             // max(msb, floor) - 4
+    const uint32_t sg = k.c_seg - min(c, k.c_seg);              // max(msb, f) - f
+    const uint32_t step = ((uint32_t)mag >> shift) & 15u;
+    return ((sg << 4) | step) ^ k.base ^ ((uint32_t)sign & 0x80u);
+}
+
+// ----------------------------------------------------------------------------
+// Table-driven form of the same compressor (what production G.711 encoders do): 2 laws x 16 384 cells of
+// one byte in LDS, a cell = four neighbouring PCM values on which the compressor is constant:
+//   SUN16 works on sign / magnitude      -> cell = (v < 0, |v| >> 2)         (|v| >> 2 clamped to 8191)
+//   G191  works on the floored 14-bit value -> cell = (v >> 2) + 8192
+// The table is generated at kernel start by running enc_uni on one representative value per cell.
+// ----------------------------------------------------------------------------
+constexpr int kEncCells = 16384;
+
+template <int VARIANT>
+__device__ __forceinline__ uint32_t enc_cell(int v)
+{
+    if (VARIANT == IGDSP_ENC_SUN16) {
+        const int sign = v >> 31;
+        const int av = (v ^ sign) - sign;
+        return ((uint32_t)sign & 8192u) + min((uint32_t)av >> 2, 8191u);
+    }
+    return (uint32_t)((v >> 2) + 8192);
+}
+
+template <int VARIANT>
+__device__ __forceinline__ int enc_cell_value(uint32_t cell)
+{
+    if (VARIANT == IGDSP_ENC_SUN16) {
+        const int k = (int)(cell & 8191u);
+        return (cell & 8192u) ? -(4 * k + 1) : 4 * k;          // (neg, k = 0) is {-1,-2,-3}: zero is never negative
+    }
+    return ((int)cell - 8192) * 4;
+}
+
+template <int VARIANT>
+__device__ __forceinline__ void fill_enc_table(uint8_t *tab)     // tab[2][kEncCells]: mu-law, A-law
+{
+    const EncK ku = enc_consts<VARIANT>(false), ka = enc_consts<VARIANT>(true);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kEncCells; i += blockDim.x) {
+        const int v = enc_cell_value<VARIANT>(i);
+        tab[i] = (uint8_t)enc_uni<VARIANT>(v, ku);
+        tab[kEncCells + i] = (uint8_t)enc_uni<VARIANT>(v, ka);
+    }
+}
+
+// Diagnostic/test entry: the table-driven compressor on arbitrary PCM (exhaustive parity test of the cells).
+template <int VARIANT>
+__global__ __launch_bounds__(1024) void k_encode_table(const int16_t *__restrict__ pcm, const uint8_t *__restrict__ codec,
+                                                       uint32_t C, uint32_t n, uint64_t n_samples, uint8_t *__restrict__ out)
+{
+    __shared__ uint8_t tab[2 * kEncCells];
+    fill_enc_table<VARIANT>(tab);
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = (uint32_t)((i / n) % C);
+        out[i] = tab[(codec[c] == IGDSP_PT_PCMA ? kEncCells : 0) + enc_cell<VARIANT>((int)pcm[i])];
+    }
+}
+
+// 8 samples (16 B) per lane in, 8 codes (8 B) out; requires n % 8 == 0 and 16 B aligned pcm.
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_encode_v8(const int16_t *__restrict__ pcm, const uint8_t *__restrict__ codec,
+                                                   uint32_t C, uint32_t n, uint64_t n_groups, uint8_t *__restrict__ out)
+{
+    const uint32_t groups_per_frame = n >> 3;
+    auto encode_group = [&](uint64_t g, const uint4 d) {
+        const uint32_t c = (uint32_t)((g / groups_per_frame) % C);
+        const EncK k = enc_consts<VARIANT>(codec[c] == IGDSP_PT_PCMA);
+        const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+        uint32_t r[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r[2 * i] = enc_uni<VARIANT>((int)(int16_t)(w[i] & 0xFFFFu), k);
+            r[2 * i + 1] = enc_uni<VARIANT>((int)(int16_t)(w[i] >> 16), k);
+        }
+        uint2 o;
+        o.x = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+        o.y = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
+        reinterpret_cast<uint2 *>(out)[g] = o;
+    };
+    // four independent 16-byte loads in flight per lane (one per quarter of the grid-stride step)
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4 *src = reinterpret_cast<const uint4 *>(pcm);
+    for (; g + 3u * stride < n_groups; g += 4u * stride) {
+        const uint4 d0 = ld_stream(src + g), d1 = ld_stream(src + g + stride), d2 = ld_stream(src + g + 2u * stride),
+                    d3 = ld_stream(src + g + 3u * stride);
+        encode_group(g, d0); encode_group(g + stride, d1); encode_group(g + 2u * stride, d2); encode_group(g + 3u * stride, d3);
+    }
+    for (; g < n_groups; g += stride) encode_group(g, ld_stream(src + g));
+}
+
+// Same 8-samples-per-lane geometry with the table-driven compressor (2 x 16 384 one-byte cells in LDS, built per
+// block by enc_uni): ~8 VALU + one LDS byte read per sample instead of ~20 VALU, which moves the encode kernel from
+// VALU-bound towards the copy-like HBM bound.  Persistent blocks so the 32 KiB table is built 2 x CUs times only.
+template <int VARIANT>
+__global__ __launch_bounds__(1024) void k_encode_v8_table(const int16_t *__restrict__ pcm, const uint8_t *__restrict__ codec,
+                                                          uint32_t C, uint32_t n, uint64_t n_groups, uint8_t *__restrict__ out)
+{
+    __shared__ uint8_t tab[2 * kEncCells];
+    fill_enc_table<VARIANT>(tab);
+    __syncthreads();
+    const uint32_t groups_per_frame = n >> 3;
+    auto encode_group = [&](uint64_t g, const uint4 d) {
+        const uint32_t c = (uint32_t)((g / groups_per_frame) % C);
+        const uint8_t *t = tab + (codec[c] == IGDSP_PT_PCMA ? kEncCells : 0);
+        const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+        uint32_t r[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r[2 * i] = t[enc_cell<VARIANT>((int)(int16_t)(w[i] & 0xFFFFu))];
+            r[2 * i + 1] = t[enc_cell<VARIANT>((int)(int16_t)(w[i] >> 16))];
+        }
+        uint2 o;
+        o.x = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+        o.y = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
+        reinterpret_cast<uint2 *>(out)[g] = o;
+    };
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4 *src = reinterpret_cast<const uint4 *>(pcm);
+    for (; g + 3u * stride < n_groups; g += 4u * stride) {
+        const uint4 d0 = ld_stream(src + g), d1 = ld_stream(src + g + stride), d2 = ld_stream(src + g + 2u * stride),
+                    d3 = ld_stream(src + g + 3u * stride);
+        encode_group(g, d0); encode_group(g + stride, d1); encode_group(g + 2u * stride, d2); encode_group(g + 3u * stride, d3);
+    }
+    for (; g < n_groups; g += stride) encode_group(g, ld_stream(src + g));
+}
+
+// Large batches: the compressor as a FULL 16-bit table, tab[law][uint16(v)] = 128 KiB of LDS built per block by
+// enc_uni (one block per CU, 16 waves).  The whole LDS address {law, v.hi, v.lo} is one v_perm_b32 of the loaded
+// PCM word, so a sample costs ~2 VALU + one ds_read_u8 and the kernel sits on the copy-like HBM bound.  Frame /
+// channel bookkeeping is incremental (adds and compares): the grid-stride step is decomposed once per thread into
+// whole frames + groups, so no division runs inside the loop.
+template <int VARIANT>
+__global__ __launch_bounds__(1024) void k_encode_lut16(const int16_t *__restrict__ pcm, const uint8_t *__restrict__ codec,
+                                                       uint32_t C, uint32_t n, uint32_t n_groups, uint8_t *__restrict__ out,
+                                                       uint32_t *gqueue)
+{
+    constexpr int kW = 16;                                         // launched with 1024 threads
+    __shared__ uint8_t tab[2 * 65536];
+    __shared__ BlockQueue<kW> bq;
+    uint32_t gb1 = 0;
+    if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);
+    {
+        const EncK ku = enc_consts<VARIANT>(false), ka = enc_consts<VARIANT>(true);
+        for (uint32_t i = threadIdx.x; i < 2u * 65536u; i += blockDim.x)
+            tab[i] = (uint8_t)enc_uni<VARIANT>((int)(int16_t)(i & 0xFFFFu), (i >> 16) ? ka : ku);
+    }
+    if (threadIdx.x == 0) bq_init(bq, gqueue, gridDim.x, gb1);
+    __syncthreads();
+    const uint32_t gpf = n >> 3;                                   // 8-sample groups per frame
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, G = gridDim.x;
+    auto encode_group = [&](uint32_t gi, const uint4 d, uint32_t pt) {
+        const uint32_t law = pt == IGDSP_PT_PCMA ? 1u : 0u;        // becomes address byte 2: +64 KiB
+        const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+        uint32_t r[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r[2 * i] = tab[__builtin_amdgcn_perm(w[i], law, 0x0C000504u)];
+            r[2 * i + 1] = tab[__builtin_amdgcn_perm(w[i], law, 0x0C000706u)];
+        }
+        uint2 o;
+        o.x = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+        o.y = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
+        reinterpret_cast<uint2 *>(out)[gi] = o;
+    };
+    const uint4 *src = reinterpret_cast<const uint4 *>(pcm);
+    // A wave takes 8 KiB chunks (kP pieces of 64 x 16 B, contiguous) from the block / device work queue (batches of 16
+    // neighbouring chunks); piece j's register is reloaded from the wave's next chunk as soon as piece j is encoded.
+    constexpr int kP = 8;
+    constexpr uint32_t kChunkGroups = 64u * kP;
+    const uint32_t n_chunks = n_groups / kChunkGroups;
+    // channel of piece j of a chunk = channel of its piece 0 advanced by 64 j groups: wave-uniform (frames, groups) steps
+    uint32_t d_r[kP], d_c[kP];
+#pragma unroll
+    for (int j = 0; j < kP; ++j) { d_r[j] = (64u * j) % gpf; d_c[j] = ((64u * j) / gpf) % C; }
+    auto channels_of = [&](uint32_t chunk, uint32_t (&cc)[kP]) {
+        const uint32_t g0 = chunk * kChunkGroups + lane, f = g0 / gpf, gin0 = g0 - f * gpf, c0 = f % C;
+#pragma unroll
+        for (int j = 0; j < kP; ++j) {
+            uint32_t gi = gin0 + d_r[j], c = c0 + d_c[j];
+            if (gi >= gpf) c += 1u;
+            if (c >= C) c -= C;
+            cc[j] = c;
+        }
+    };
+    const uint32_t n_batches = (n_chunks + (uint32_t)kW - 1u) / (uint32_t)kW;
+    uint32_t chunk = spread_batch(blockIdx.x, n_batches) * (uint32_t)kW + wave;
+    if (chunk < n_chunks) {
+        uint4 d[kP];
+        uint32_t pt[kP], cc[kP];
+        channels_of(chunk, cc);
+#pragma unroll
+        for (int j = 0; j < kP; ++j) { d[j] = ld_stream(src + (chunk * kChunkGroups + lane + 64u * j)); pt[j] = codec[cc[j]]; }
+        uint32_t next = bq_grab(bq, gqueue, G, lane, n_batches);
+        for (;;) {
+            const bool has_next = next < n_chunks;
+            const uint32_t nl = has_next ? next : chunk;           // last round re-reads itself: loads stay unconditional
+            const uint32_t gl = nl * kChunkGroups + lane, gs = chunk * kChunkGroups + lane;
+            channels_of(nl, cc);
+#pragma unroll
+            for (int j = 0; j < kP; ++j) {
+                encode_group(gs + 64u * j, d[j], pt[j]);
+                d[j] = ld_stream(src + (gl + 64u * j));
+                pt[j] = codec[cc[j]];
+            }
+            if (!has_next) break;
+            chunk = next;
+            next = bq_grab(bq, gqueue, G, lane, n_batches);
+        }
+    }
+    // groups beyond the last whole chunk (< 512): plain grid-stride
+    for (uint32_t g = n_chunks * kChunkGroups + blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x)
+        encode_group(g, src[g], codec[(g / gpf) % C]);
+    bq_finish(gqueue, G);
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_encode_scalar(const int16_t *__restrict__ pcm, const uint8_t *__restrict__ codec,
+                                                       uint32_t C, uint32_t n, uint64_t n_samples, uint8_t *__restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = (uint32_t)((i / n) % C);
+        out[i] = (uint8_t)enc_uni<VARIANT>((int)pcm[i], enc_consts<VARIANT>(codec[c] == IGDSP_PT_PCMA));
+    }
+}
+
+// Merge one work item's window into hold[c] when several items share a channel (frame segments): device-scope integer
+// atomics (adds, and a CAS loop on the {peak_hold, level_max, level_min} word) — exact and order-independent, so the
+// result is bit-identical to the sequential fold (keeplogAudioLevel, Functions.cpp:2126-2145).
+__device__ __forceinline__ void hold_merge(igdsp_chan_hold *g, const igdsp_chan_hold &h)
+{
+    atomicAdd((unsigned long long *)&g->sumsq_acc, (unsigned long long)h.sumsq_acc);
+    atomicAdd(&g->count, h.count); atomicAdd(&g->level_sum, h.level_sum); atomicAdd(&g->samples, h.samples);
+    atomicAdd(&g->n_silent, h.n_silent); atomicAdd(&g->n_clipped, h.n_clipped);
+    uint32_t *pw = reinterpret_cast<uint32_t *>(&g->peak_hold);
+    uint32_t old = *pw, want;
+    do {
+        const uint32_t pk = max(old & 0xFFFFu, (uint32_t)h.peak_hold), mx = max((old >> 16) & 0xFFu, (uint32_t)h.level_max);
+        const uint32_t mn = min(old >> 24, (uint32_t)h.level_min);
+        want = pk | (mx << 16) | (mn << 24);
+        if (want == old) break;
+        const uint32_t seen = atomicCAS(pw, old, want);
+        if (seen == old) break;
+        old = seen;
+    } while (true);
+}
+
+// ============================================================================
+// Config #5 — fused decode -> stats -> re-encode -> per-channel hold (a1 + a2 + a5 + a6).
+// Channel-group-major: one wavefront owns 64 consecutive CHANNELS and walks all F frames of them
+// (frame f of those channels is one contiguous 10 240-byte super-chunk at stride C*160), so the hold
+// state — keeplogAudioLevel's count / sum / max / min (Functions.cpp:2126-2145) plus peak-hold and
+// sum of squares — lives in the frame lanes' registers for the whole launch and is written once.
+// Same LUT, strip and load pipeline as k_meter_chunk64; the re-encode is the full compression
+// arithmetic (enc_uni) applied to the decoded PCM value, not a shortcut.  Needs C % 64 == 0, n == 160.
+// ============================================================================
+#ifndef IGDSP_RT_WAVES
+#define IGDSP_RT_WAVES 12
+#endif
+constexpr int kRtWaves = IGDSP_RT_WAVES;
+// LDS map of k_roundtrip_chunk64 (158 KiB of the CU's 160 KiB), chosen so that both table addresses come out
+// of the instruction stream without adds:
+//   [  0,  32 KiB)  compressor grid table  tab[law][neg][k] = enc(neg ? -4k : 4k), one byte per cell
+//   [ 32,  62 KiB)  strips of waves 0..5
+//   [ 64, 128 KiB)  expansion LUT; entry = {(|x|/4)^2, slot of the compressor cell of (law, |x|/4)}
+//   [128, 158 KiB)  strips of waves 6..11
+// Every G.711 expander output is a multiple of 4 with |x| <= 32256, so (law, sign, |x| / 4) enumerates the
+// compressor's whole input domain on this path; the table holds the compressor (enc_uni, the same arithmetic
+// igdsp_encode runs) evaluated at exactly those PCM values.  -0 (mu-law code 0x7F) lands in cell (neg, 0),
+// which holds enc(0), as two's-complement PCM would.
+constexpr uint32_t kRtEncBytes = 32768u, kRtLutOff = 65536u, kRtStripBytes = (uint32_t)kStripEntries * 8u;
+constexpr uint32_t kRtStripA = kRtEncBytes, kRtStripB = kRtLutOff + (uint32_t)kLutEntries * 8u;
+constexpr uint32_t kRtLdsBytes = kRtStripB + (uint32_t)(kRtWaves - kRtWaves / 2) * kRtStripBytes;
+static_assert(kRtStripA + (uint32_t)(kRtWaves / 2) * kRtStripBytes <= kRtLutOff, "strips A overlap the LUT");
+static_assert(kRtLdsBytes <= 160u * 1024u, "LDS budget");
+
+// Slot of compressor cell t = law << 14 | k inside its 16 KiB half-table: t ^ (t >> 4).  G.711 expander outputs of the
+// upper segments differ only in high bits of k (k = (2m + 33) * 2^s - 33), so with slot = k every mantissa of a segment
+// lands in the SAME LDS bank (PMC: 66 % of the LDS cycles of this kernel were bank conflicts); folding the high bits into
+// the bank bits takes the average cost of a 32-lane byte read from 3.9 to 2.5 cycles on D-speech.  A bijection on 15 bits
+// that never touches bit 13 (the sign is OR-ed in afterwards).
+__device__ __forceinline__ uint32_t rt_cell_slot(uint32_t t) { return t ^ (t >> 4); }
+
+template <int VARIANT>
+__device__ __forceinline__ void fill_rt_tables(uint8_t *smem)
+{
+    const EncK ku = enc_consts<VARIANT>(false), ka = enc_consts<VARIANT>(true);
+    for (uint32_t i = threadIdx.x; i < kRtEncBytes; i += blockDim.x) {
+        const int k = (int)(i & 8191u);
+        const int v = (i & 8192u) ? -4 * k : 4 * k;
+        smem[rt_cell_slot(i & ~8192u) | (i & 8192u)] = (uint8_t)enc_uni<VARIANT>(v, (i & 16384u) ? ka : ku);
+    }
+    uint2 *lut = reinterpret_cast<uint2 *>(smem + kRtLutOff);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kLutEntries; i += blockDim.x) {
+        const uint32_t e = i >> 5;                 // law<<7 | code7
+        const uint32_t ax = (e & 0x80u) ? alaw_abs(e) : ulaw_abs(e);
+        const uint32_t m = ax >> 2;
+        lut[i] = make_uint2(m * m, rt_cell_slot(((e & 0x80u) << 7) | m));   // {(|x|/4)^2, slot of compressor cell (law, |x|/4)}
+    }
+}
+
+// One half (32 frames) of a super-chunk.  Three-stage software pipeline per unit of 8 samples:
+//   expansion-LUT reads of unit u+1 in flight | unit u folded, its 8 compressor-cell reads issued | unit u-1 packed
+// `offx` = replica offset | 0x100: the 0x01 in byte 1 becomes address byte 2 (the LUT's 64 KiB base) inside the v_perm.
+template <int VARIANT>
+__device__ __forceinline__ void roundtrip_half(const uint8_t *smem, uint2 *strip_half, uint4 (&d)[kLoadsPerChunk],
+                                               const uint32_t (&lm)[kLoadsPerChunk], const uint32_t (&pm)[kLoadsPerChunk],
+                                               const uint32_t offx, const uint32_t lane, uint4 *out_half, const uint4 *refill)
+{
+    uint2 e[2][8];
+    uint32_t wa[2], wb[2], eb[2][8];
+    auto lut = [&](uint32_t t, uint32_t sel) {
+        return *reinterpret_cast<const uint2 *>(smem + __builtin_amdgcn_perm(t, offx, sel));
+    };
+    auto issue = [&](int u) {
+        const int j = u >> 1, k = u & 1;
+        wa[k] = (u & 1) ? d[j].z : d[j].x;
+        wb[k] = (u & 1) ? d[j].w : d[j].y;
+        const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lm[j], tb = (wb[k] & 0x7F7F7F7Fu) | lm[j];
+        e[k][0] = lut(ta, 0x0C010400u); e[k][1] = lut(ta, 0x0C010500u); e[k][2] = lut(ta, 0x0C010600u); e[k][3] = lut(ta, 0x0C010700u);
+        e[k][4] = lut(tb, 0x0C010400u); e[k][5] = lut(tb, 0x0C010500u); e[k][6] = lut(tb, 0x0C010600u); e[k][7] = lut(tb, 0x0C010700u);
+    };
+    // compressor cell of sample i of word w: its slot comes straight from entry.y, the sign from the code
+    auto cells = [&](uint32_t w, const uint2 &e0, const uint2 &e1, const uint2 &e2, const uint2 &e3, uint32_t *dst) {
+        const uint32_t nw = ~w & 0x80808080u;                    // bit 8i+7 set: sample i is negative
+        dst[0] = smem[((nw << 6) & 0x2000u) | e0.y];
+        dst[1] = smem[((nw >> 2) & 0x2000u) | e1.y];
+        dst[2] = smem[((nw >> 10) & 0x2000u) | e2.y];
+        dst[3] = smem[((nw >> 18) & 0x2000u) | e3.y];
+    };
+    auto pack = [&](const uint32_t *b) { return b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24); };
+    uint32_t sum = 0, peak = 0, bsum = 0;
+    uint32_t o[4];
+    issue(0);
+#pragma unroll
+    for (int u = 0; u <= 2 * kLoadsPerChunk; ++u) {
+        const int j = u >> 1, k = u & 1;
+        if (u + 1 < 2 * kLoadsPerChunk) issue(u + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u < 2 * kLoadsPerChunk) {
+            bsum = __builtin_amdgcn_sad_u8(wa[k], 0u, bsum);
+            bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
+            sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
+            sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
+            peak = max(max(peak, e[k][0].x), e[k][1].x); peak = max(max(peak, e[k][2].x), e[k][3].x);   // max of (|x|/4)^2
+            peak = max(max(peak, e[k][4].x), e[k][5].x); peak = max(max(peak, e[k][6].x), e[k][7].x);
+            cells(wa[k], e[k][0], e[k][1], e[k][2], e[k][3], &eb[k][0]);
+            cells(wb[k], e[k][4], e[k][5], e[k][6], e[k][7], &eb[k][4]);
+            if (k == 1) {
+                // peak |x| = 4 * sqrt(max (|x|/4)^2), (|x|/4) <= 8064
+                const uint32_t pk = (uint32_t)(__builtin_amdgcn_sqrtf((float)peak) + 0.5f) << 2;   // (float)peak and v_sqrt_f32 are each within 1 ulp: round, never truncate
+                strip_half[j * 64 + lane] = make_uint2(sum, pk | (bsum << 16) | probe_fail(d[j], pm[j]));
+                d[j] = ld_stream(refill + j * 64);
+                sum = 0; peak = 0; bsum = 0;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (u >= 1) {                                            // unit u-1: its cell bytes have had a whole fold to arrive
+            const int jp = (u - 1) >> 1, kp = (u - 1) & 1;
+            o[2 * kp] = pack(&eb[kp][0]);
+            o[2 * kp + 1] = pack(&eb[kp][4]);
+            if (kp == 1) st_stream(out_half + jp * 64, make_uint4(o[0], o[1], o[2], o[3]));
+        }
+    }
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(kRtWaves * 64) void k_roundtrip_chunk64(
+    const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F,
+    uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats, igdsp_chan_hold *__restrict__ hold,
+    const uint8_t *__restrict__ gate, uint32_t n_seg, uint32_t n_groups)
+{
+    // Work item = (channel group of 64, frame segment): with 65 536 channels there are only 1 024 groups, so the
+    // launcher splits the F frames into n_seg segments to fill the chip.  n_seg == 1: the wave owns its channels'
+    // hold records outright (plain read-modify-write).  n_seg > 1: each item folds its own window and MERGES it into
+    // hold[c] with device-scope integer atomics (adds, and a CAS loop on the {peak_hold, max, min} word) —
+    // exact and order-independent, so the result is bit-identical to the sequential fold.
+    __shared__ __attribute__((aligned(16))) uint8_t smem[kRtLdsBytes];
+    fill_rt_tables<VARIANT>(smem);
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2 *strip = reinterpret_cast<uint2 *>(smem + (wave < (uint32_t)(kRtWaves / 2) ? kRtStripA + wave * kRtStripBytes
+                                                                                     : kRtStripB + (wave - (uint32_t)(kRtWaves / 2)) * kRtStripBytes));
+    const uint32_t offx = (lane & 31u) * 8u | 0x100u;
+    uint32_t fr[kLoadsPerChunk], pm[kLoadsPerChunk];
+#pragma unroll
+    for (int j = 0; j < kLoadsPerChunk; ++j) {
+        const uint32_t p = (uint32_t)j * 64u + lane;
+        fr[j] = p / 10u;
+        pm[j] = probe_mask(p - fr[j] * 10u);
+    }
+    const uint32_t total_waves = gridDim.x * kRtWaves;
+    const uint32_t fstride16 = C * (uint32_t)kPiecesPerFrame;       // uint4 units between frames of one channel group
+
+    for (uint32_t item = wave * gridDim.x + blockIdx.x; item < n_groups * n_seg; item += total_waves) {
+        const uint32_t seg = item / n_groups, cg = item - seg * n_groups;
+        const uint32_t f_lo = (uint32_t)(((uint64_t)F * seg) / n_seg), f_hi = (uint32_t)(((uint64_t)F * (seg + 1u)) / n_seg);
+        if (f_lo >= f_hi) continue;
+        const uint32_t c0 = cg * kSuperFrames, cme = c0 + lane;
+        const bool my_alaw = codec[cme] == IGDSP_PT_PCMA;
+        const bool open = (gate == nullptr) || (gate[cme] != 0);
+        igdsp_chan_hold h;
+        if (n_seg == 1u) h = hold[cme];
+        else { h.sumsq_acc = 0; h.count = 0; h.level_sum = 0; h.samples = 0; h.peak_hold = 0; h.level_max = 0; h.level_min = 255; h.n_silent = 0; h.n_clipped = 0; }
+        const uint64_t amask = __ballot(my_alaw);
+        const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
+        uint32_t lm0[kLoadsPerChunk], lm1[kLoadsPerChunk];
+#pragma unroll
+        for (int j = 0; j < kLoadsPerChunk; ++j) {
+            lm0[j] = (uint32_t)__builtin_amdgcn_sbfe(am_lo, fr[j], 1) & 0x80808080u;
+            lm1[j] = (uint32_t)__builtin_amdgcn_sbfe(am_hi, fr[j], 1) & 0x80808080u;
+        }
+        const uint4 *src = reinterpret_cast<const uint4 *>(payload) + ((uint64_t)c0 * kPiecesPerFrame + lane);
+        uint4 *dst = reinterpret_cast<uint4 *>(out) + ((uint64_t)c0 * kPiecesPerFrame + lane);
+
+        uint4 X[kLoadsPerChunk], Y[kLoadsPerChunk];
+#pragma unroll
+        for (int j = 0; j < kLoadsPerChunk; ++j) X[j] = ld_stream(src + (uint64_t)f_lo * fstride16 + j * 64);
+#pragma unroll
+        for (int j = 0; j < kLoadsPerChunk; ++j) Y[j] = ld_stream(src + (uint64_t)f_lo * fstride16 + kPiecesPerChunk + j * 64);
+
+        for (uint32_t f = f_lo; f < f_hi; ++f) {
+            const bool more = f + 1u < f_hi;                    // wave-uniform; the last frame re-reads itself (cache hit)
+            const uint4 *nsrc = src + (uint64_t)(more ? f + 1u : f) * fstride16;
+            uint4 *o16 = dst + (uint64_t)f * fstride16;
+            roundtrip_half<VARIANT>(smem, strip, X, lm0, pm, offx, lane, o16, nsrc);
+            roundtrip_half<VARIANT>(smem, strip + kPiecesPerChunk, Y, lm1, pm, offx, lane, o16 + kPiecesPerChunk, nsrc + kPiecesPerChunk);
+            wave_lds_fence();
+            {
+                const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kPiecesPerFrame);
+                uint64_t s = 0;
+                uint32_t peak = 0, bsum = 0, fail = 0;
+#pragma unroll
+                for (int i = 0; i < kPiecesPerFrame / 2; ++i) {
+                    const uint4 v = row[i];
+                    s += (uint64_t)(v.x + v.z);
+                    peak = max(max(peak, v.y & 0x7FFFu), v.w & 0x7FFFu);
+                    bsum += ((v.y >> 16) & 0x7FFFu) + ((v.w >> 16) & 0x7FFFu);
+                    fail |= v.y | v.w;
+                }
+                uint32_t bm, fl;
+                st_stream(reinterpret_cast<uint4 *>(stats + ((uint64_t)f * C + cme)), pack_stats160(s, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl));
+                if (open) {
+                    h.sumsq_acc += s << 4; h.count += 1u; h.level_sum += bm; h.samples += (uint32_t)kFrame;
+                    h.peak_hold = (uint16_t)max((uint32_t)h.peak_hold, peak);
+                    h.level_max = (uint8_t)max((uint32_t)h.level_max, bm);
+                    h.level_min = (uint8_t)min((uint32_t)h.level_min, bm);
+                    h.n_silent += (fl & IGDSP_FLAG_SILENT) ? 1u : 0u;
+                    h.n_clipped += (fl & IGDSP_FLAG_CLIPPED) ? 1u : 0u;
+                }
+            }
+            wave_lds_fence();
+        }
+        if (n_seg == 1u) hold[cme] = h;
+        else if (h.count != 0u) hold_merge(hold + cme, h);
+    }
+}
+
+// ============================================================================
+// Config #5, default form — k_roundtrip_lut64: the same channel-group-major walk as k_roundtrip_chunk64 with the
+// compressor folded INTO the expansion LUT.  A G.711 code has 256 values per law, so decode -> re-encode is a function
+// of (law, code): at kernel start every block evaluates the real expander and the real compressor (enc_uni, the
+// arithmetic igdsp_encode runs) on each of the 2 x 128 magnitudes, once for +|x| and once for -|x|, and stores
+//     entry = { (|x|/4)^2 ,  enc(-|x|) | enc(+|x|) << 8 | |x| << 16 }
+// in the 32-replica conflict-free layout of fill_lut.  Per sample the kernel then does ONE ds_read_b64 (as the meter) and
+// the re-encoded byte is picked by the code's sign bit with v_perm_b32 (3 perms + 2 VALU per 4 samples); the second LDS
+// read per sample of the cell-table form (whose bank conflicts kept the LDS 80 % busy) is gone, and the
+// frame peak comes from max(entry.y) >> 16 (the low bytes only break ties).  mu-law 0x7F ("-0") decodes to PCM 0 and
+// re-encodes as enc(0) = 0xFF, exactly as two's-complement PCM between a real decoder and encoder would.
+// ============================================================================
+#ifndef IGDSP_RTL_WAVES
+#define IGDSP_RTL_WAVES 12
+#endif
+constexpr int kRtlWaves = IGDSP_RTL_WAVES;
+
+template <int VARIANT>
+__device__ __forceinline__ void fill_recode_lut(uint2 *lut)
+{
+    const EncK ku = enc_consts<VARIANT>(false), ka = enc_consts<VARIANT>(true);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kLutEntries; i += blockDim.x) {
+        const uint32_t e = i >> 5;                 // law<<7 | code7
+        const bool alaw = (e & 0x80u) != 0u;
+        const uint32_t ax = alaw ? alaw_abs(e) : ulaw_abs(e);
+        const uint32_t m = ax >> 2;
+        const uint32_t en = enc_uni<VARIANT>(-(int)ax, alaw ? ka : ku), ep = enc_uni<VARIANT>((int)ax, alaw ? ka : ku);
+        lut[i] = make_uint2(m * m, en | (ep << 8) | (ax << 16));
+    }
+}
+
+// Per-lane piece constants of a half, packed: five 5-bit frame indices (frame-in-half of piece j) in `fr5`, five 5-bit probe
+// shifts in `pm5` (the probe byte a piece is responsible for sits at that bit of probe_fail's gathered word; 24 = none, that
+// byte of the word is always zero).  Two registers instead of ten; one v_bfe_u32 (+ one shift) per piece to unpack.
+__device__ __forceinline__ void pack_piece_consts(uint32_t lane, uint32_t &fr5, uint32_t &pm5)
+{
+    fr5 = 0; pm5 = 0;
+#pragma unroll
+    for (int j = 0; j < kLoadsPerChunk; ++j) {
+        const uint32_t p = (uint32_t)j * 64u + lane, f = p / 10u, q = p - f * 10u;
+        const uint32_t sh = q == 1u ? 0u : (q == 3u ? 8u : (q == 2u ? 16u : 24u));
+        fr5 |= f << (5 * j);
+        pm5 |= sh << (5 * j);
+    }
+}
+
+// One half (32 frames) of a super-chunk: expand, meter, re-encode.  Same software pipeline as process_half (the LUT reads
+// of unit u + 1 are in flight while unit u is folded); the eight re-encoded bytes of a unit are assembled right in its fold.
+// All memory traffic goes through buffer instructions: `rin` describes the NEXT frame's super-chunk (refill), `rout` this
+// frame's output super-chunk; `voff` = lane * 16, `hoff` = byte offset of the half inside the super-chunk.
+__device__ __forceinline__ void recode_half(const uint2 *lut, uint2 *strip_half, uint4 (&d)[kLoadsPerChunk], const uint32_t am,
+                                            const uint32_t fr5, const uint32_t pm5, const uint32_t off, const uint32_t lane,
+                                            const uint32_t voff, const uint32_t hoff, __amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rout)
+{
+    uint2 e[2][8];
+    uint32_t wa[2], wb[2];
+    auto issue = [&](int u) {
+        const int j = u >> 1, k = u & 1;
+        wa[k] = (u & 1) ? d[j].z : d[j].x;
+        wb[k] = (u & 1) ? d[j].w : d[j].y;
+        const uint32_t frj = __builtin_amdgcn_ubfe(fr5, 5 * j, 5);
+        const uint32_t lmj = (uint32_t)__builtin_amdgcn_sbfe(am, frj, 1) & 0x80808080u;
+        const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lmj, tb = (wb[k] & 0x7F7F7F7Fu) | lmj;
+        e[k][0] = lut_at(lut, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lut, ta, off, 0x0C0C0500u);
+        e[k][2] = lut_at(lut, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lut, ta, off, 0x0C0C0700u);
+        e[k][4] = lut_at(lut, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lut, tb, off, 0x0C0C0500u);
+        e[k][6] = lut_at(lut, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lut, tb, off, 0x0C0C0700u);
+    };
+    // four re-encoded bytes of word w: entries' byte 0 = enc(-|x|), byte 1 = enc(+|x|); a code is positive iff its bit 7 is set
+    auto recode4 = [&](uint32_t w, const uint2 &e0, const uint2 &e1, const uint2 &e2, const uint2 &e3) {
+        const uint32_t p01 = __builtin_amdgcn_perm(e1.y, e0.y, 0x05040100u);       // [e0.neg, e0.pos, e1.neg, e1.pos]
+        const uint32_t p23 = __builtin_amdgcn_perm(e3.y, e2.y, 0x05040100u);
+        const uint32_t sel = ((w >> 7) & 0x01010101u) | 0x06040200u;              // byte i picks pair i, +1 when positive
+        return __builtin_amdgcn_perm(p23, p01, sel);
+    };
+    uint32_t sum = 0, peak = 0, bsum = 0;
+    uint32_t o[4];
+    issue(0);
+#pragma unroll
+    for (int u = 0; u < 2 * kLoadsPerChunk; ++u) {
+        const int j = u >> 1, k = u & 1;
+        if (u + 1 < 2 * kLoadsPerChunk) issue(u + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        bsum = __builtin_amdgcn_sad_u8(wa[k], 0u, bsum);
+        bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
+        sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
+        sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
+        peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);   // |x| << 16 dominates the compare
+        peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
+        o[2 * k] = recode4(wa[k], e[k][0], e[k][1], e[k][2], e[k][3]);
+        o[2 * k + 1] = recode4(wb[k], e[k][4], e[k][5], e[k][6], e[k][7]);
+        if (k == 1) {
+            const uint32_t pmj = 0xFFu << __builtin_amdgcn_ubfe(pm5, 5 * j, 5);
+            strip_half[j * 64 + lane] = make_uint2(sum, (peak >> 16) | (bsum << 16) | probe_fail(d[j], pmj));
+            buf_st(rout, voff, hoff + (uint32_t)j * 1024u, make_uint4(o[0], o[1], o[2], o[3]));
+            d[j] = buf_ld_stream(rin, voff, hoff + (uint32_t)j * 1024u);
+            sum = 0; peak = 0; bsum = 0;
+        }
+    }
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_lut64(
+    const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F,
+    uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats, igdsp_chan_hold *__restrict__ hold,
+    const uint8_t *__restrict__ gate, uint32_t n_seg, uint32_t n_groups, uint32_t order)
+{
+    // Work item = (group of 64 consecutive channels, segment of the F frames), as in k_roundtrip_chunk64: n_seg == 1 ->
+    // the wave owns hold[c] outright; n_seg > 1 -> windows merge by device-scope integer atomics (exact, order-free).
+    // n_groups = C / 64 channel groups are handled here; channels beyond 64 * n_groups (C % 64) belong to the general kernel.
+    __shared__ uint2 lds[kLutEntries + kRtlWaves * kStripEntries];
+    fill_recode_lut<VARIANT>(lds);
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint2 *strip = lds + kLutEntries + wave * kStripEntries;
+    const uint32_t off = (lane & 31u) * 8u, voff = lane * 16u;
+    uint32_t fr5, pm5;
+    pack_piece_consts(lane, fr5, pm5);
+    const uint32_t total_waves = gridDim.x * kRtlWaves;
+    const uint64_t fbytes = (uint64_t)C * kFrame;                  // bytes between two frames of one channel group
+
+    // order 0: the waves of a block take items a grid apart (neighbouring BLOCKS touch neighbouring groups); order 1: the
+    // waves of a block take consecutive items (one block touches kRtlWaves neighbouring groups = 120 KiB per frame)
+    const uint32_t first = order ? blockIdx.x * (uint32_t)kRtlWaves + wave : wave * gridDim.x + blockIdx.x;
+    for (uint32_t item = first; item < n_groups * n_seg; item += total_waves) {
+        const uint32_t seg = item / n_groups, cg = item - seg * n_groups;
+        const uint32_t f_lo = (uint32_t)(((uint64_t)F * seg) / n_seg), f_hi = (uint32_t)(((uint64_t)F * (seg + 1u)) / n_seg);
+        if (f_lo >= f_hi) continue;
+        const uint32_t c0 = cg * kSuperFrames, cme = c0 + lane;
+        const bool my_alaw = codec[cme] == IGDSP_PT_PCMA;
+        const bool open = (gate == nullptr) || (gate[cme] != 0);
+        // the window of this item, packed: {peak_hold | level_max << 16} (packed 16-bit max), level_min, {n_silent | n_clipped << 16}
+        // (a segment never has 65 536 frames: launcher), level_sum, sumsq; count = frames of the segment if the gate is open
+        uint64_t h_sumsq = 0;
+        uint32_t h_pm = 0, h_min = 255u, h_sc = 0, h_lsum = 0;
+        const uint64_t amask = __ballot(my_alaw);
+        const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
+        const uint8_t *in0 = payload + (uint64_t)c0 * kFrame;     // wave-uniform bases: frame f of this group sits f * fbytes further
+        uint8_t *out0 = out + (uint64_t)c0 * kFrame;
+
+        uint4 X[kLoadsPerChunk], Y[kLoadsPerChunk];
+        {
+            const __amdgpu_buffer_rsrc_t r0 = make_rsrc(in0 + (uint64_t)f_lo * fbytes);
+#pragma unroll
+            for (int j = 0; j < kLoadsPerChunk; ++j) X[j] = buf_ld_stream(r0, voff, (uint32_t)j * 1024u);
+#pragma unroll
+            for (int j = 0; j < kLoadsPerChunk; ++j) Y[j] = buf_ld_stream(r0, voff, (uint32_t)kChunkBytes + (uint32_t)j * 1024u);
+        }
+        for (uint32_t f = f_lo; f < f_hi; ++f) {
+            const bool more = f + 1u < f_hi;                    // wave-uniform; the last frame re-reads itself (cache hit)
+            const __amdgpu_buffer_rsrc_t rin = make_rsrc(in0 + (uint64_t)(more ? f + 1u : f) * fbytes);
+            const __amdgpu_buffer_rsrc_t rout = make_rsrc(out0 + (uint64_t)f * fbytes);
+            recode_half(lds, strip, X, am_lo, fr5, pm5, off, lane, voff, 0u, rin, rout);
+            recode_half(lds, strip + kPiecesPerChunk, Y, am_hi, fr5, pm5, off, lane, voff, (uint32_t)kChunkBytes, rin, rout);
+            wave_lds_fence();
+            {
+                const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kPiecesPerFrame);
+                uint64_t sq = 0;
+                uint32_t peak = 0, bsum = 0, fail = 0;
+#pragma unroll
+                for (int i = 0; i < kPiecesPerFrame / 2; ++i) {
+                    const uint4 v = row[i];
+                    sq += (uint64_t)(v.x + v.z);
+                    peak = max(max(peak, v.y & 0x7FFFu), v.w & 0x7FFFu);
+                    bsum += ((v.y >> 16) & 0x7FFFu) + ((v.w >> 16) & 0x7FFFu);
+                    fail |= v.y | v.w;
+                }
+                uint32_t bm, fl;
+                const uint4 rec = pack_stats160(sq, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl);
+                buf_st(make_rsrc(stats + ((uint64_t)f * C + c0)), voff, 0u, rec);       // 64 records = 1 KiB, lane * 16
+                h_sumsq += sq << 4; h_lsum += bm;
+                h_pm = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16_t, h_pm), __builtin_bit_cast(v2u16_t, peak | (bm << 16))));
+                h_min = min(h_min, bm);
+                h_sc += ((fl & IGDSP_FLAG_SILENT) ? 1u : 0u) + ((fl & IGDSP_FLAG_CLIPPED) ? 0x10000u : 0u);
+            }
+            wave_lds_fence();
+        }
+        if (open) {
+            igdsp_chan_hold h;
+            const uint32_t cnt = f_hi - f_lo;
+            h.sumsq_acc = h_sumsq; h.count = cnt; h.level_sum = h_lsum; h.samples = cnt * (uint32_t)kFrame;
+            h.peak_hold = (uint16_t)(h_pm & 0xFFFFu); h.level_max = (uint8_t)(h_pm >> 16); h.level_min = (uint8_t)h_min;
+            h.n_silent = h_sc & 0xFFFFu; h.n_clipped = h_sc >> 16;
+            if (n_seg == 1u) {                                   // the wave owns hold[c]: plain read-modify-write
+                igdsp_chan_hold g = hold[cme];
+                g.sumsq_acc += h.sumsq_acc; g.count += h.count; g.level_sum += h.level_sum; g.samples += h.samples;
+                g.peak_hold = max(g.peak_hold, h.peak_hold); g.level_max = max(g.level_max, h.level_max); g.level_min = min(g.level_min, h.level_min);
+                g.n_silent += h.n_silent; g.n_clipped += h.n_clipped;
+                hold[cme] = g;
+            } else hold_merge(hold + cme, h);
+        }
+    }
+}
+
+// ============================================================================
+// Config #5 at the reference's other frame sizes — k_roundtrip_strided<Q, TAIL>: k_roundtrip_lut64's channel-group-major walk
+// (hold window in registers, frame segments, atomic merge) over frames of n = 16 Q + 4 T bytes with k_meter_strided's piece
+// geometry: Q + TAIL pieces per frame fetched at dword alignment through buffer instructions, the tail piece handing the
+// frame's last dwords raw to the frame lane (stats) and storing their re-encoded bytes itself (output).
+// ============================================================================
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int Q, bool TAIL, int VARIANT>
+__global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
+    const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F, uint32_t n,
+    uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats, igdsp_chan_hold *__restrict__ hold,
+    const uint8_t *__restrict__ gate, uint32_t n_seg, uint32_t n_groups)
+{
+    static_assert(Q == 1 || Q >= 4, "the probe bytes 28 / 38 / 48 are taken from pieces 1 / 2 / 3");
+    constexpr int QP = Q + (TAIL ? 1 : 0);
+    constexpr int kStrip = kSuperFrames * QP;
+    __shared__ uint2 lds[kLutEntries + kRtlWaves * kStrip];
+    fill_recode_lut<VARIANT>(lds);
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint2 *strip = lds + kLutEntries + wave * kStrip;
+    const uint32_t off = (lane & 31u) * 8u;
+    const uint32_t T = (n - 16u * Q) >> 2;
+    constexpr int kPk = (QP + 1) / 2;
+    uint32_t pk[kPk];
+#pragma unroll
+    for (int j = 0; j < kPk; ++j) pk[j] = 0;
+#pragma unroll
+    for (int j = 0; j < QP; ++j) {
+        const uint32_t p = (uint32_t)j * 64u + lane, f = p / (uint32_t)QP, q = p - f * (uint32_t)QP;
+        const uint32_t sh = q == 1u ? 0u : (q == 3u ? 8u : (q == 2u ? 16u : 24u));
+        pk[j >> 1] |= (f | (((TAIL && q == (uint32_t)Q) ? 24u : sh) << 8) | ((TAIL && q == (uint32_t)Q) ? 0x2000u : 0u)) << (16 * (j & 1));
+    }
+    auto fr_of = [&](int j) { return __builtin_amdgcn_ubfe(pk[j >> 1], 16 * (j & 1), 6); };
+    auto ps_of = [&](int j) { return __builtin_amdgcn_ubfe(pk[j >> 1], 16 * (j & 1) + 8, 5); };
+    auto tail_of = [&](int j) { return TAIL && ((pk[j >> 1] >> (16 * (j & 1) + 13)) & 1u) != 0u; };
+    auto po_of = [&](int j) {                                    // byte offset of this lane's piece j inside a 64-channel frame row
+        const uint32_t f = fr_of(j), q = (uint32_t)j * 64u + lane - f * (uint32_t)QP;
+        return f * n + (tail_of(j) ? n - 16u : 16u * q);
+    };
+    const uint32_t total_waves = gridDim.x * kRtlWaves;
+    const uint64_t fbytes = (uint64_t)C * n;                       // bytes between two frames of one channel group
+
+    for (uint32_t item = wave * gridDim.x + blockIdx.x; item < n_groups * n_seg; item += total_waves) {
+        const uint32_t seg = item / n_groups, cg = item - seg * n_groups;
+        const uint32_t f_lo = (uint32_t)(((uint64_t)F * seg) / n_seg), f_hi = (uint32_t)(((uint64_t)F * (seg + 1u)) / n_seg);
+        if (f_lo >= f_hi) continue;
+        const uint32_t c0 = cg * kSuperFrames, cme = c0 + lane;
+        const bool my_alaw = codec[cme] == IGDSP_PT_PCMA;
+        const bool open = (gate == nullptr) || (gate[cme] != 0);
+        uint64_t h_sumsq = 0;
+        uint32_t h_pm = 0, h_min = 255u, h_sc = 0, h_lsum = 0;
+        const uint64_t amask = __ballot(my_alaw);
+        const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
+        const uint8_t *in0 = payload + (uint64_t)c0 * n;
+        uint8_t *out0 = out + (uint64_t)c0 * n;
+
+        uint4 d[QP];
+        {
+            const __amdgpu_buffer_rsrc_t r0 = make_rsrc(in0 + (uint64_t)f_lo * fbytes);
+#pragma unroll
+            for (int j = 0; j < QP; ++j) d[j] = buf_ld_stream(r0, po_of(j), 0u);
+        }
+        for (uint32_t f = f_lo; f < f_hi; ++f) {
+            const bool more = f + 1u < f_hi;
+            const __amdgpu_buffer_rsrc_t rin = make_rsrc(in0 + (uint64_t)(more ? f + 1u : f) * fbytes);
+            const __amdgpu_buffer_rsrc_t rout = make_rsrc(out0 + (uint64_t)f * fbytes);
+#pragma unroll
+            for (int j = 0; j < kPk; ++j) asm volatile("" : "+v"(pk[j]));
+            {
+                uint2 e[2][8];
+                uint32_t wa[2], wb[2];
+                auto issue = [&](int u) {
+                    const int j = u >> 1, k = u & 1;
+                    wa[k] = (u & 1) ? d[j].z : d[j].x;
+                    wb[k] = (u & 1) ? d[j].w : d[j].y;
+                    const uint32_t frj = fr_of(j);
+                    const uint32_t bit = frj < 32u ? (uint32_t)__builtin_amdgcn_sbfe(am_lo, frj, 1) : (uint32_t)__builtin_amdgcn_sbfe(am_hi, frj - 32u, 1);
+                    const uint32_t lmj = bit & 0x80808080u;
+                    const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lmj, tb = (wb[k] & 0x7F7F7F7Fu) | lmj;
+                    e[k][0] = lut_at(lds, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lds, ta, off, 0x0C0C0500u);
+                    e[k][2] = lut_at(lds, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lds, ta, off, 0x0C0C0700u);
+                    e[k][4] = lut_at(lds, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lds, tb, off, 0x0C0C0500u);
+                    e[k][6] = lut_at(lds, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lds, tb, off, 0x0C0C0700u);
+                };
+                auto recode4 = [&](uint32_t w, const uint2 &e0, const uint2 &e1, const uint2 &e2, const uint2 &e3) {
+                    const uint32_t p01 = __builtin_amdgcn_perm(e1.y, e0.y, 0x05040100u);
+                    const uint32_t p23 = __builtin_amdgcn_perm(e3.y, e2.y, 0x05040100u);
+                    const uint32_t sel = ((w >> 7) & 0x01010101u) | 0x06040200u;
+                    return __builtin_amdgcn_perm(p23, p01, sel);
+                };
+                uint32_t sum = 0, peak = 0, bsum = 0;
+                uint32_t o[4];
+                issue(0);
+#pragma unroll
+                for (int u = 0; u < 2 * QP; ++u) {
+                    const int j = u >> 1, k = u & 1;
+                    if (u + 1 < 2 * QP) issue(u + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    bsum = __builtin_amdgcn_sad_u8(wa[k], 0u, bsum);
+                    bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
+                    sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
+                    sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
+                    peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
+                    peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
+                    o[2 * k] = recode4(wa[k], e[k][0], e[k][1], e[k][2], e[k][3]);
+                    o[2 * k + 1] = recode4(wb[k], e[k][4], e[k][5], e[k][6], e[k][7]);
+                    if (k == 1) {
+                        uint2 ent = make_uint2(sum, (peak >> 16) | (bsum << 16) | probe_fail(d[j], 0xFFu << ps_of(j)));
+                        const uint32_t pj = po_of(j);
+                        if (tail_of(j)) {
+                            ent = make_uint2(d[j].z, d[j].w);                   // the frame's last two dwords, raw, for the frame lane
+                            const uint32_t to = fr_of(j) * n + 16u * Q;         // the tail's re-encoded bytes go right behind piece Q - 1
+                            if (T == 2u) { u32x2_t v; v.x = o[2]; v.y = o[3]; __builtin_amdgcn_raw_buffer_store_b64(v, rout, (int)to, 0, 0); }
+                            else __builtin_amdgcn_raw_buffer_store_b32(o[3], rout, (int)to, 0, 0);
+                        } else buf_st(rout, pj, 0u, make_uint4(o[0], o[1], o[2], o[3]));
+                        strip[j * 64 + lane] = ent;
+                        d[j] = buf_ld_stream(rin, pj, 0u);
+                        sum = 0; peak = 0; bsum = 0;
+                    }
+                }
+            }
+            wave_lds_fence();
+            {
+                const uint2 *row = strip + lane * QP;
+                uint64_t sq = 0;
+                uint32_t peak = 0, bsum = 0, fail = 0, part = 0;
+#pragma unroll
+                for (int i = 0; i < Q; ++i) {
+                    const uint2 v = row[i];
+                    part += v.x;
+                    if ((i & 3) == 3 || i == Q - 1) { sq += part; part = 0; }
+                    peak = max(peak, v.y & 0x7FFFu);
+                    bsum += (v.y >> 16) & 0x7FFFu;
+                    fail |= v.y;
+                }
+                if (TAIL) {
+                    const uint2 tv = row[Q];
+                    const uint32_t lm = my_alaw ? 0x80808080u : 0u;
+                    const uint32_t tws[2] = {T == 2u ? tv.x : tv.y, tv.y};
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        if ((uint32_t)t < T) {
+                            const uint32_t w = tws[t], tt = (w & 0x7F7F7F7Fu) | lm;
+                            const uint2 e0 = lut_at(lds, tt, off, 0x0C0C0400u), e1 = lut_at(lds, tt, off, 0x0C0C0500u);
+                            const uint2 e2 = lut_at(lds, tt, off, 0x0C0C0600u), e3 = lut_at(lds, tt, off, 0x0C0C0700u);
+                            sq += (uint64_t)(e0.x + e1.x + e2.x + e3.x);
+                            peak = max(peak, max(max(e0.y, e1.y), max(e2.y, e3.y)) >> 16);
+                            bsum = __builtin_amdgcn_sad_u8(w, 0u, bsum);
+                        }
+                }
+                uint32_t bm, fl;
+                const uint4 rec = pack_stats(sq << 4, peak, bsum, n, my_alaw, (Q >= 4) && (fail >> 31) == 0u, bm, fl);
+                buf_st(make_rsrc(stats + ((uint64_t)f * C + c0)), lane * 16u, 0u, rec);
+                h_sumsq += sq << 4; h_lsum += bm;
+                h_pm = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16_t, h_pm), __builtin_bit_cast(v2u16_t, peak | (bm << 16))));
+                h_min = min(h_min, bm);
+                h_sc += ((fl & IGDSP_FLAG_SILENT) ? 1u : 0u) + ((fl & IGDSP_FLAG_CLIPPED) ? 0x10000u : 0u);
+            }
+            wave_lds_fence();
+        }
+        if (open) {
+            igdsp_chan_hold h;
+            const uint32_t cnt = f_hi - f_lo;
+            h.sumsq_acc = h_sumsq; h.count = cnt; h.level_sum = h_lsum; h.samples = cnt * n;
+            h.peak_hold = (uint16_t)(h_pm & 0xFFFFu); h.level_max = (uint8_t)(h_pm >> 16); h.level_min = (uint8_t)h_min;
+            h.n_silent = h_sc & 0xFFFFu; h.n_clipped = h_sc >> 16;
+            if (n_seg == 1u) {
+                igdsp_chan_hold g = hold[cme];
+                g.sumsq_acc += h.sumsq_acc; g.count += h.count; g.level_sum += h.level_sum; g.samples += h.samples;
+                g.peak_hold = max(g.peak_hold, h.peak_hold); g.level_max = max(g.level_max, h.level_max); g.level_min = min(g.level_min, h.level_min);
+                g.n_silent += h.n_silent; g.n_clipped += h.n_clipped;
+                hold[cme] = g;
+            } else hold_merge(hold + cme, h);
+        }
+    }
+}
+
+// ============================================================================
+// Config #5 for every other shape — k_roundtrip_general: one wavefront per CHANNEL walks that channel's F frames
+// (any n in 1..256, any C, unaligned buffers), lane l owning bytes [4l, 4l + 4) of a frame as in
+// k_meter_wave_per_frame.  Decode through the signed 256-entry LUT, stats by wave reduction, re-encode with the full
+// compressor arithmetic (enc_uni) on the decoded PCM, window aggregate in registers, hold[c] written once.  It serves
+// BASELINE config #1's 4 channels, 164- or 24-byte frames, and the C % 64 channels the fused kernel leaves over
+// (channels [c_first, c_first + c_count) of a [F][C][n] batch).
+// ============================================================================
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_roundtrip_general(
+    const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F, uint32_t n,
+    uint32_t c_first, uint32_t c_count, uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats,
+    igdsp_chan_hold *__restrict__ hold, const uint8_t *__restrict__ gate)
+{
+    __shared__ int16_t lut[2][256];
+    for (uint32_t i = threadIdx.x; i < 512u; i += 256u) {
+        const uint32_t code = i & 255u;
+        const int ax = (int)((i >> 8) ? alaw_abs(code) : ulaw_abs(code));
+        lut[i >> 8][code] = (int16_t)((code & 0x80u) ? ax : -ax);
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const bool dword_ok = ((n & 3u) == 0u) && (((reinterpret_cast<uintptr_t>(payload) | reinterpret_cast<uintptr_t>(out)) & 3u) == 0u);
+    const uint32_t b0 = lane * 4u;
+    const uint32_t nvalid = (n > b0) ? min(n - b0, 4u) : 0u;
+    for (uint32_t ci = blockIdx.x * 4u + wave; ci < c_count; ci += gridDim.x * 4u) {
+        const uint32_t c = c_first + ci;
+        const bool alaw = codec[c] == IGDSP_PT_PCMA;
+        const bool open = (gate == nullptr) || (gate[c] != 0);
+        const EncK ek = enc_consts<VARIANT>(alaw);
+        igdsp_chan_hold h = hold[c];                              // wave-uniform copy; lane 0 writes it back
+        auto load_frame = [&](uint32_t f) -> uint32_t {
+            const uint8_t *base = payload + ((uint64_t)f * C + c) * n;
+            uint32_t w = 0;
+            if (dword_ok) { if (b0 < n) w = *reinterpret_cast<const uint32_t *>(base + b0); }
+            else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) if (k < nvalid) w |= (uint32_t)base[b0 + k] << (8u * k);
+            }
+            return w;
+        };
+        uint32_t w = load_frame(0);
+        for (uint32_t f = 0; f < F; ++f) {
+            const uint32_t wn = load_frame(min(f + 1u, F - 1u));  // next frame in flight while this one is folded
+            uint32_t sum = 0, peak = 0, bsum = 0, o = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t b = (w >> (8u * k)) & 255u;
+                const int v = (k < nvalid) ? (int)lut[alaw][b] : 0;
+                const uint32_t ax = (uint32_t)(v < 0 ? -v : v);
+                sum += (ax >> 2) * (ax >> 2);
+                peak = max(peak, ax);
+                bsum += (k < nvalid) ? b : 0u;
+                o |= enc_uni<VARIANT>(v, ek) << (8u * k);        // the compressor on the decoded PCM value
+            }
+            if (b0 < n) {
+                uint8_t *ob = out + ((uint64_t)f * C + c) * n + b0;
+                if (dword_ok) *reinterpret_cast<uint32_t *>(ob) = o;
+                else {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; ++k) if (k < nvalid) ob[k] = (uint8_t)(o >> (8u * k));
+                }
+            }
+            const uint32_t w7 = (uint32_t)__builtin_amdgcn_readlane((int)w, 7), w9 = (uint32_t)__builtin_amdgcn_readlane((int)w, 9),
+                           w12 = (uint32_t)__builtin_amdgcn_readlane((int)w, 12);
+            const bool probe = (n > 48u) && ((w7 & 255u) == 0xD5u) && (((w9 >> 16) & 255u) == 0xD5u) && ((w12 & 255u) == 0xD5u);
+            const uint32_t r_lo = wave_reduce_dpp(sum & 0xFFFFu, OpAdd()), r_hi = wave_reduce_dpp(sum >> 16, OpAdd());
+            const uint64_t s64 = (((uint64_t)r_hi << 16) + r_lo) << 4;
+            peak = wave_reduce_dpp(peak, OpMax());
+            bsum = wave_reduce_dpp(bsum, OpAdd());
+            const igdsp_frame_stats st = make_stats(s64, peak, bsum, n, alaw, probe);
+            if (lane == 0) stats[(uint64_t)f * C + c] = st;
+            if (open) {
+                h.sumsq_acc += s64; h.count += 1u; h.level_sum += st.byte_mean; h.samples += n;
+                h.peak_hold = (uint16_t)max((uint32_t)h.peak_hold, peak);
+                h.level_max = (uint8_t)max((uint32_t)h.level_max, (uint32_t)st.byte_mean);
+                h.level_min = (uint8_t)min((uint32_t)h.level_min, (uint32_t)st.byte_mean);
+                h.n_silent += (st.flags & IGDSP_FLAG_SILENT) ? 1u : 0u;
+                h.n_clipped += (st.flags & IGDSP_FLAG_CLIPPED) ? 1u : 0u;
+            }
+            w = wn;
+        }
+        if (lane == 0) hold[c] = h;
+    }
+}
+
+// a6 — fold stats[f][c] into hold[c]; one thread per channel, coalesced over c.
+__global__ __launch_bounds__(256) void k_hold_update(const igdsp_frame_stats *__restrict__ stats,
+                                                     const uint16_t *__restrict__ len, uint32_t C, uint32_t F,
+                                                     uint32_t n, igdsp_chan_hold *__restrict__ hold,
+                                                     const uint8_t *__restrict__ gate)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (gate != nullptr && gate[c] == 0) return;
+    igdsp_chan_hold h = hold[c];
+    for (uint32_t f = 0; f < F; ++f) {
+        const igdsp_frame_stats s = stats[(uint64_t)f * C + c];
+        if (s.flags & IGDSP_FLAG_EMPTY) continue;
+        h.sumsq_acc += s.sumsq; h.count += 1u; h.level_sum += s.byte_mean;
+        h.samples += len ? min((uint32_t)len[(uint64_t)f * C + c], n) : n;
+        h.peak_hold = (uint16_t)max((uint32_t)h.peak_hold, (uint32_t)s.peak);
+        h.level_max = (uint8_t)max((uint32_t)h.level_max, (uint32_t)s.byte_mean);
+        h.level_min = (uint8_t)min((uint32_t)h.level_min, (uint32_t)s.byte_mean);
+        h.n_silent += (s.flags & IGDSP_FLAG_SILENT) ? 1u : 0u;
+        h.n_clipped += (s.flags & IGDSP_FLAG_CLIPPED) ? 1u : 0u;
+    }
+    hold[c] = h;
+}
+
+// a6 on the drop-in path: fold the records of one flush into hold[c].  The flush compacts every channel's staged frames
+// into consecutive records ("runs": {channel, first record, count}); one thread per run folds them in arrival order
+// (keeplogAudioLevel per frame, Functions.cpp:2126-2145).
+__global__ __launch_bounds__(256) void k_hold_fold_runs(const igdsp_frame_stats *__restrict__ stats, const uint16_t *__restrict__ len,
+                                                        uint32_t n, const uint32_t *__restrict__ runs, uint32_t n_runs,
+                                                        igdsp_chan_hold *__restrict__ hold)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_runs) return;
+    const uint32_t c = runs[3 * r], first = runs[3 * r + 1], count = runs[3 * r + 2];
+    igdsp_chan_hold h = hold[c];
+    for (uint32_t i = first; i < first + count; ++i) {
+        const igdsp_frame_stats s = stats[i];
+        if (s.flags & IGDSP_FLAG_EMPTY) continue;
+        h.sumsq_acc += s.sumsq; h.count += 1u; h.level_sum += s.byte_mean;
+        h.samples += len ? min((uint32_t)len[i], n) : n;
+        h.peak_hold = (uint16_t)max((uint32_t)h.peak_hold, (uint32_t)s.peak);
+        h.level_max = (uint8_t)max((uint32_t)h.level_max, (uint32_t)s.byte_mean);
+        h.level_min = (uint8_t)min((uint32_t)h.level_min, (uint32_t)s.byte_mean);
+        h.n_silent += (s.flags & IGDSP_FLAG_SILENT) ? 1u : 0u;
+        h.n_clipped += (s.flags & IGDSP_FLAG_CLIPPED) ? 1u : 0u;
+    }
+    hold[c] = h;
+}
+
+__global__ __launch_bounds__(256) void k_hold_reset(igdsp_chan_hold *__restrict__ hold, uint32_t C,
+                                                    const uint8_t *__restrict__ mask)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (mask != nullptr && mask[c] == 0) return;
+    igdsp_chan_hold h;
+    h.sumsq_acc = 0; h.count = 0; h.level_sum = 0; h.samples = 0; h.peak_hold = 0;
+    h.level_max = 0; h.level_min = 255; h.n_silent = 0; h.n_clipped = 0;
+    hold[c] = h;
+}
+
+hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t *codec, uint32_t C, uint32_t F,
+                         uint32_t n, uint8_t *out, int variant, hipStream_t s)
+{
+    const uint64_t n_samples = (uint64_t)C * F * n;
+    if (n_samples == 0) return hipSuccess;
+    const bool v8 = ((n & 7u) == 0u) && ((reinterpret_cast<uintptr_t>(pcm) & 15u) == 0u) &&
+                    ((reinterpret_cast<uintptr_t>(out) & 7u) == 0u);
+    const uint32_t cap = (uint32_t)cfg.compute_units * 8u;
+    if (v8 && n_samples >= (1u << 25) && (n_samples >> 3) < 0xFFFF0000ull) {   // large batches: full 16-bit table, one block per CU (32-bit group ids)
+        const uint32_t groups = (uint32_t)(n_samples >> 3);    // 32-bit group ids (checked above)
+        const uint32_t grid = blocks_for(groups, 1024, (uint32_t)cfg.compute_units);
+        if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_G191>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, groups, out, cfg.gqueue);
+        else                           hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_SUN16>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, groups, out, cfg.gqueue);
+    } else if (v8 && n_samples >= (1u << 22)) {                 // big batches: table-driven compressor, persistent blocks
+        const uint64_t groups = n_samples >> 3;
+        const uint32_t grid = blocks_for(groups, 1024, (uint32_t)cfg.compute_units * 2u);
+        if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_v8_table<IGDSP_ENC_G191>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, groups, out);
+        else                           hipLaunchKernelGGL((k_encode_v8_table<IGDSP_ENC_SUN16>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, groups, out);
+    } else if (v8) {
+        const uint64_t groups = n_samples >> 3;
+        const uint32_t grid = blocks_for(groups, 256, cap);
+        if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_v8<IGDSP_ENC_G191>), dim3(grid), dim3(256), 0, s, pcm, codec, C, n, groups, out);
+        else                           hipLaunchKernelGGL((k_encode_v8<IGDSP_ENC_SUN16>), dim3(grid), dim3(256), 0, s, pcm, codec, C, n, groups, out);
+    } else {
+        const uint32_t grid = blocks_for(n_samples, 256, cap);
+        if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_scalar<IGDSP_ENC_G191>), dim3(grid), dim3(256), 0, s, pcm, codec, C, n, n_samples, out);
+        else                           hipLaunchKernelGGL((k_encode_scalar<IGDSP_ENC_SUN16>), dim3(grid), dim3(256), 0, s, pcm, codec, C, n, n_samples, out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_encode_table(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t *codec, uint32_t C, uint32_t F, uint32_t n,
+                               uint8_t *out, int variant, hipStream_t s)
+{
+    const uint64_t n_samples = (uint64_t)C * F * n;
+    if (n_samples == 0) return hipSuccess;
+    const uint32_t grid = blocks_for(n_samples, 1024 * 16, (uint32_t)cfg.compute_units);
+    if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_table<IGDSP_ENC_G191>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, n_samples, out);
+    else                           hipLaunchKernelGGL((k_encode_table<IGDSP_ENC_SUN16>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, n_samples, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F,
+                            uint32_t n, uint8_t *out, igdsp_frame_stats *stats, igdsp_chan_hold *hold,
+                            const uint8_t *gate, int variant, hipStream_t s)
+{
+    if ((uint64_t)C * F == 0) return hipSuccess;
+    // The fused channel-group-major kernels take whole groups of 64 channels of 160-byte frames in 16-byte aligned
+    // buffers; the C % 64 channels left over, and every other shape (n != 160, unaligned buffers), go through
+    // k_roundtrip_general on the same stream.  kernel_variant 4 selects the compressor-cell-table form of the fused
+    // kernel (k_roundtrip_chunk64, kept for A/B runs); the default folds the compressor into the expansion LUT.
+    const bool aligned = ((reinterpret_cast<uintptr_t>(payload) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(stats)) & 15u) == 0u;
+    // the reference's other frame sizes (24, 80, 164 / 168, 240; dword-aligned buffers suffice) keep the fused walk: k_roundtrip_strided
+    const uint32_t Qn = n >> 4, Tn = (n >> 2) & 3u;
+    const bool strided = kernel_variant != 1 && n != (uint32_t)kFrame && (n & 3u) == 0u && Tn != 3u && n >= 16u &&
+                         (((reinterpret_cast<uintptr_t>(payload) | reinterpret_cast<uintptr_t>(out)) & 3u) == 0u) && ((reinterpret_cast<uintptr_t>(stats) & 15u) == 0u) &&
+                         ((Qn == 1u && Tn != 0u) || (Qn == 5u && Tn == 0u) || (Qn == 10u && Tn != 0u) || (Qn == 15u && Tn == 0u));
+    if (strided && C >= (uint32_t)kSuperFrames) {
+        const uint32_t n_groups_s = C / kSuperFrames;
+        const uint32_t want = (uint32_t)cfg.compute_units * (uint32_t)kRtlWaves;
+        uint32_t n_seg = n_groups_s >= want ? 1u : (want + n_groups_s - 1u) / n_groups_s;
+        n_seg = std::max(1u, std::min(n_seg, std::max(1u, F / 8u)));
+        n_seg = std::max(n_seg, F / 65535u + 1u);
+        const uint32_t grid = blocks_for((uint64_t)n_groups_s * n_seg, kRtlWaves, (uint32_t)cfg.compute_units);
+        const dim3 g3(grid), b3(kRtlWaves * 64);
+#define IGDSP_RTS(QV, TV)                                                                                                                                      \
+        if (Qn == QV && (Tn != 0u) == TV) {                                                                                                                     \
+            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_G191>), g3, b3, 0, s, payload, codec, C, F, n, out, stats, hold, gate, n_seg, n_groups_s);  \
+            else                           hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_SUN16>), g3, b3, 0, s, payload, codec, C, F, n, out, stats, hold, gate, n_seg, n_groups_s); \
+        }
+        IGDSP_RTS(1, true) IGDSP_RTS(5, false) IGDSP_RTS(10, true) IGDSP_RTS(15, false)
+#undef IGDSP_RTS
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const uint32_t c_first = n_groups_s * (uint32_t)kSuperFrames, c_count = C - c_first;
+        if (c_count != 0u) {
+            const uint32_t gridg = blocks_for(c_count, 4, (uint32_t)cfg.compute_units * 8u);
+            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_general<IGDSP_ENC_G191>), dim3(gridg), dim3(256), 0, s, payload, codec, C, F, n, c_first, c_count, out, stats, hold, gate);
+            else                           hipLaunchKernelGGL((k_roundtrip_general<IGDSP_ENC_SUN16>), dim3(gridg), dim3(256), 0, s, payload, codec, C, F, n, c_first, c_count, out, stats, hold, gate);
+        }
+        return hipGetLastError();
+    }
+    const uint32_t n_groups = (n == (uint32_t)kFrame && aligned && kernel_variant != 1) ? C / kSuperFrames : 0u;
+    if (n_groups != 0u) {
+        // fill the chip: at least one work item per resident wave; a segment is never shorter than 8 frames
+        const int waves = kernel_variant == 4 ? kRtWaves : kRtlWaves;
+        const uint32_t want = (uint32_t)cfg.compute_units * (uint32_t)waves;
+        uint32_t n_seg = n_groups >= want ? 1u : (want + n_groups - 1u) / n_groups;
+        if (const char *e = std::getenv("IGDSP_RT_NSEG")) n_seg = (uint32_t)std::max(1, std::atoi(e));   // experiments
+        n_seg = std::max(1u, std::min(n_seg, std::max(1u, F / 8u)));
+        n_seg = std::max(n_seg, F / 65535u + 1u);               // the fused kernels count silent / clipped frames of a segment in 16 bits
+        uint32_t order = 0;
+        if (const char *e = std::getenv("IGDSP_RT_ORDER")) order = (uint32_t)std::atoi(e);
+        const uint32_t grid = blocks_for((uint64_t)n_groups * n_seg, waves, (uint32_t)cfg.compute_units);
+        if (kernel_variant == 4) {
+            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_G191>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);
+            else                           hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_SUN16>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);
+        } else {
+            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_lut64<IGDSP_ENC_G191>), dim3(grid), dim3(kRtlWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups, order);
+            else                           hipLaunchKernelGGL((k_roundtrip_lut64<IGDSP_ENC_SUN16>), dim3(grid), dim3(kRtlWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups, order);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t c_first = n_groups * (uint32_t)kSuperFrames, c_count = C - c_first;
+    if (c_count != 0u) {
+        const uint32_t grid = blocks_for(c_count, 4, (uint32_t)cfg.compute_units * 8u);
+        if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_general<IGDSP_ENC_G191>), dim3(grid), dim3(256), 0, s, payload, codec, C, F, n, c_first, c_count, out, stats, hold, gate);
+        else                           hipLaunchKernelGGL((k_roundtrip_general<IGDSP_ENC_SUN16>), dim3(grid), dim3(256), 0, s, payload, codec, C, F, n, c_first, c_count, out, stats, hold, gate);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_hold_update(const igdsp_frame_stats *stats, const uint16_t *len, uint32_t C, uint32_t F, uint32_t n,
+                              igdsp_chan_hold *hold, const uint8_t *gate, hipStream_t s)
+{
+    if (C == 0 || F == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_hold_update, dim3((C + 255) / 256), dim3(256), 0, s, stats, len, C, F, n, hold, gate);
+    return hipGetLastError();
+}
+
+hipError_t launch_hold_fold_runs(const igdsp_frame_stats *stats, const uint16_t *len, uint32_t n, const uint32_t *runs, uint32_t n_runs,
+                                 igdsp_chan_hold *hold, hipStream_t s)
+{
+    if (n_runs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_hold_fold_runs, dim3((n_runs + 255) / 256), dim3(256), 0, s, stats, len, n, runs, n_runs, hold);
+    return hipGetLastError();
+}
+
+hipError_t launch_hold_reset(igdsp_chan_hold *hold, uint32_t C, const uint8_t *mask, hipStream_t s)
+{
+    if (C == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_hold_reset, dim3((C + 255) / 256), dim3(256), 0, s, hold, C, mask);
+    return hipGetLastError();
+}
+
+
+}  // namespace igdsp

@@ -1,0 +1,517 @@
+// igdsp_k_packets.hip — the packet side: fused depayload + decode + meter (k_meter_rtp64) and ED-137 depayload + gather (k_depayload*).
+// Hand-written gfx950 (CDNA4, wave64) kernels; no MFMA: the path is a byte stream with ~4 integer ops per sample, bounded by
+// HBM.  Shared device code: igdsp_device.h.
+#include "igdsp_device.h"
+
+namespace igdsp {
+
+// ============================================================================
+// Fused packet path — k_meter_rtp64: depayload + decode + meter in one pass over 192-byte packet slots
+// (include/igdsp.h, igdsp_decode_meter_rtp).  Same machinery as k_meter_chunk64 with 12 pieces per
+// slot instead of 10: pieces 0 and 1 of a slot are {size, pad, RTP bytes 0-3} and {RTP bytes 4-19}; they
+// run through the pipeline like payload (wasted LUT work on 1/6 of the pieces) but their strip entries
+// carry header words instead of partial sums, so the slot's frame lane sees PT / size / ED-137 word at
+// fold time and either emits the record or marks the frame EMPTY.  Reads 192 B per frame where the
+// two-kernel pipeline (depayload then meter) moves 180 + 160 + 160 + records.
+// ============================================================================
+constexpr int kSlotPieces = IGDSP_SLOT_BYTES / 16;                 // 12
+constexpr int kRtpHalfLoads = kSlotPieces * kChunkFrames / 64;     // 6 loads per lane per 32-slot half
+constexpr int kRtpStrip = kSuperFrames * kSlotPieces;              // 768 entries = 6 KiB per wave
+constexpr int kRtpWaves = 12;                                      // 64 KiB LUT + 72 KiB strips
+
+// SLOT = true : 192-byte slots (size word + pad + packet at +12), every piece 16-byte aligned.
+// SLOT = false: packets packed at `stride` bytes exactly as received; piece addresses are only dword aligned.
+// MIXED: payload pieces of the NEXT item's radio packets (bit fr[j] of `nrm`, that item's radio ballot half) sit 8 bytes
+// further; the offset is formed at refill time so no per-item offset arrays stay live.
+template <bool SLOT, bool MIXED = false>
+__device__ __forceinline__ void rtp_half(const uint2 *lut, uint2 *strip_half, uint4 (&d)[kRtpHalfLoads],
+                                         const uint32_t am, const uint32_t (&fr)[kRtpHalfLoads], const uint32_t (&pm)[kRtpHalfLoads],
+                                         const uint32_t (&hs)[kRtpHalfLoads], const uint32_t off, const uint32_t lane,
+                                         const uint8_t *refill_base, const uint32_t (&roff)[kRtpHalfLoads], const uint32_t nrm = 0u)
+{
+    uint2 e[2][8];
+    uint32_t wa[2], wb[2];
+    auto issue = [&](int u) {
+        const int j = u >> 1, k = u & 1;
+        wa[k] = (u & 1) ? d[j].z : d[j].x;
+        wb[k] = (u & 1) ? d[j].w : d[j].y;
+        const uint32_t lmj = (uint32_t)__builtin_amdgcn_sbfe(am, fr[j], 1) & 0x80808080u;   // law bit of this piece's packet
+        const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lmj, tb = (wb[k] & 0x7F7F7F7Fu) | lmj;
+        e[k][0] = lut_at(lut, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lut, ta, off, 0x0C0C0500u);
+        e[k][2] = lut_at(lut, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lut, ta, off, 0x0C0C0700u);
+        e[k][4] = lut_at(lut, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lut, tb, off, 0x0C0C0500u);
+        e[k][6] = lut_at(lut, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lut, tb, off, 0x0C0C0700u);
+    };
+    uint32_t sum = 0, peak = 0, bsum = 0;
+    issue(0);
+#pragma unroll
+    for (int u = 0; u < 2 * kRtpHalfLoads; ++u) {
+        const int j = u >> 1, k = u & 1;
+        if (u + 1 < 2 * kRtpHalfLoads) issue(u + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        bsum = __builtin_amdgcn_sad_u8(wa[k], 0u, bsum);
+        bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
+        sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
+        sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
+        peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
+        peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
+        if (k == 1) {
+            uint2 ent = make_uint2(sum, peak | (bsum << 16) | probe_fail(d[j], pm[j]));
+            // header pieces.  SLOT: piece 0 = slot bytes 0..15 -> {size word, RTP bytes 0-3}; piece 1 = bytes 16..31.
+            //                packed: piece 0 = packet bytes 0..15 -> {RTP bytes 0-3, -};      piece 1 = bytes 4..19.
+            // either way piece 1 ends with {extension profile/length, ED-137 word}
+            if (hs[j] == 1u) ent = SLOT ? make_uint2(d[j].x, d[j].w) : make_uint2(0u, d[j].x);
+            if (hs[j] == 2u) ent = make_uint2(d[j].z, d[j].w);
+            strip_half[j * 64 + lane] = ent;
+            const uint32_t ro = roff[j] + ((MIXED && hs[j] == 0u) ? ((nrm >> fr[j]) & 1u) * 8u : 0u);
+            d[j] = SLOT ? ld_stream(reinterpret_cast<const uint4 *>(refill_base + ro)) : ld16_dw(refill_base + ro);
+            sum = 0; peak = 0; bsum = 0;
+        }
+    }
+}
+
+// Short payloads in the fused packet kernels.  transport_rtp_cb accepts any payloadlen = size - header
+// (TransportAdapter.cpp:270-291; the hook anticipates 164 and 24, roip_ed137.cpp:6561-6562).  The pipeline above is built
+// for whole 160-byte payloads; a packet with 0 < payloadlen < 160 is rare, so its FRAME LANE re-meters it alone, straight
+// from the packet (L2-hot or re-fetched), with the same LUT: one dword per step, bytes past `len` masked out of every
+// accumulator.  Reads stay inside the packet's slot (len < 160 <= slot payload).  Costs ~25 instructions per dword in the
+// lanes that need it and one wave-uniform branch for everybody else.
+__device__ __forceinline__ void meter_short(const uint2 *lut, const uint32_t off, const uint8_t *pp, const uint32_t len, const bool alaw,
+                                            uint64_t &s, uint32_t &peak, uint32_t &bsum, bool &probe)
+{
+    const uint32_t lm = alaw ? 0x80808080u : 0u;
+    uint64_t acc = 0;
+    uint32_t pk = 0, bs = 0, fail = 0;
+    for (uint32_t i = 0; i < len; i += 4u) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(pp + i);
+        const uint32_t nv = min(len - i, 4u);
+        const uint32_t t = (w & 0x7F7F7F7Fu) | lm;
+        const uint2 e0 = lut_at(lut, t, off, 0x0C0C0400u), e1 = lut_at(lut, t, off, 0x0C0C0500u);
+        const uint2 e2 = lut_at(lut, t, off, 0x0C0C0600u), e3 = lut_at(lut, t, off, 0x0C0C0700u);
+        acc += (uint64_t)(e0.x + (nv > 1u ? e1.x : 0u) + (nv > 2u ? e2.x : 0u) + (nv > 3u ? e3.x : 0u));   // 4 x 2^26 fits u32
+        pk = max(max(pk, e0.y), max(nv > 1u ? e1.y : 0u, max(nv > 2u ? e2.y : 0u, nv > 3u ? e3.y : 0u)));
+        bs = __builtin_amdgcn_sad_u8(nv >= 4u ? w : (w & ((1u << (8u * nv)) - 1u)), 0u, bs);
+        // the reference's silence probe: payload bytes 28 / 38 / 48
+        if (i == 28u || i == 48u) fail |= (w ^ 0xD5u) & 0xFFu;
+        if (i == 36u) fail |= ((w >> 16) ^ 0xD5u) & 0xFFu;
+    }
+    s = acc; peak = pk; bsum = bs; probe = len > 48u && fail == 0u;
+}
+
+// MIXED (packed form only): the header length is per channel, 20 bytes where radio[c] != 0 and 12 elsewhere (SIP and
+// ED-137 legs in one launch, as in the reference's process); `hdr` is then ignored.  The radio flags travel like the
+// codec ids: the frame lanes fetch them one item ahead and a ballot hands every piece its packet's bit.
+template <bool AGG, bool SLOT, bool MIXED = false>
+__global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
+    const uint8_t *__restrict__ slots, const uint16_t *__restrict__ sizes, const uint8_t *__restrict__ codec, uint32_t C,
+    uint32_t n_frames, uint32_t stride, uint32_t hdr, igdsp_frame_stats *__restrict__ stats, igdsp_rtp_info *__restrict__ info,
+    igdsp_aggregate *agg, uint32_t rank, uint32_t *gqueue, const uint8_t *__restrict__ radio = nullptr)
+{
+    static_assert(!(SLOT && MIXED), "slots always hold 20-byte headers");
+    if (MIXED) hdr = 12u;
+    __shared__ uint2 lds[kLutEntries + kRtpWaves * kRtpStrip];
+    __shared__ BlockQueue<kRtpWaves> bq;
+    uint32_t gb1 = 0;
+    if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);
+    fill_lut(lds);
+    if (threadIdx.x == 0) bq_init(bq, gqueue, gridDim.x, gb1);
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2 *strip = lds + kLutEntries + wave * kRtpStrip;
+    const uint32_t off = (lane & 31u) * 8u;
+    uint32_t pm[kRtpHalfLoads], hs[kRtpHalfLoads], fr[kRtpHalfLoads];
+    uint32_t roff0[kRtpHalfLoads], roff1[kRtpHalfLoads];       // byte offset of this lane's pieces inside a super-chunk
+#pragma unroll
+    for (int j = 0; j < kRtpHalfLoads; ++j) {
+        const uint32_t p = (uint32_t)j * 64u + lane;
+        fr[j] = p / 12u;                                  // slot within the 32-slot half
+        const uint32_t q = p - fr[j] * 12u;               // piece within the slot: 0, 1 header; 2..11 payload
+        hs[j] = q < 2u ? q + 1u : 0u;
+        pm[j] = q < 2u ? 0u : probe_mask(q - 2u);
+        if (SLOT) {
+            roff0[j] = p * 16u;
+            roff1[j] = (p + (uint32_t)(kRtpStrip / 2)) * 16u;
+        } else {
+            const uint32_t po = q == 0u ? 0u : (q == 1u ? 4u : hdr + 16u * (q - 2u));
+            roff0[j] = fr[j] * stride + po;
+            roff1[j] = (fr[j] + (uint32_t)kChunkFrames) * stride + po;
+        }
+    }
+    const uint32_t G = gridDim.x;
+    const uint32_t n_super = n_frames / kSuperFrames;
+    const uint64_t super_bytes = (uint64_t)kSuperFrames * (SLOT ? (uint32_t)IGDSP_SLOT_BYTES : stride);
+    // launch-aggregate partials: per lane sum of squares, samples (< 2^32 per lane and launch), byte-mean sum, peak; the three
+    // counts are wave-uniform popcounts of ballots and live in SGPRs
+    uint64_t a_sumsq = 0;
+    uint32_t a_samp = 0, a_bm = 0, a_peak = 0;
+    uint32_t u_frames = 0, u_sil = 0, u_clip = 0;
+
+    auto fetch_radio = [&](uint32_t sidx) { return MIXED ? (uint32_t)radio[(sidx * (uint32_t)kSuperFrames + lane) % C] : 0u; };
+    // byte offsets of this lane's pieces for an item whose packets' radio bits are rm: payload pieces of radio packets sit 8 bytes further
+    auto offsets = [&](uint64_t rm, uint32_t (&o0)[kRtpHalfLoads], uint32_t (&o1)[kRtpHalfLoads]) {
+#pragma unroll
+        for (int j = 0; j < kRtpHalfLoads; ++j) {
+            const uint32_t b0 = (uint32_t)(rm >> fr[j]) & 1u, b1 = (uint32_t)(rm >> (fr[j] + 32u)) & 1u;
+            o0[j] = roff0[j] + (hs[j] == 0u ? 8u * b0 : 0u);
+            o1[j] = roff1[j] + (hs[j] == 0u ? 8u * b1 : 0u);
+        }
+    };
+    auto ld = [&](const uint8_t *b, uint32_t o) { return SLOT ? ld_stream(reinterpret_cast<const uint4 *>(b + o)) : ld16_dw(b + o); };
+    auto fetch_pt = [&](uint32_t sidx) { return (uint32_t)codec[(sidx * (uint32_t)kSuperFrames + lane) % C]; };
+    const uint32_t n_batches = IGDSP_SPREAD_METER ? (n_super + (uint32_t)kRtpWaves - 1u) / (uint32_t)kRtpWaves : 0u;   // records only: no spreading
+    auto grab = [&]() { return bq_grab(bq, gqueue, G, lane, n_batches); };
+
+    uint32_t sidx = spread_batch(blockIdx.x, n_batches) * (uint32_t)kRtpWaves + wave;     // batch blockIdx.x, slot = wave
+    if (sidx < n_super) {
+        uint4 X[kRtpHalfLoads], Y[kRtpHalfLoads];
+        uint32_t cur_pt = fetch_pt(sidx);
+        uint32_t cur_radio = fetch_radio(sidx);
+        {
+            const uint8_t *b0 = slots + (uint64_t)sidx * super_bytes;
+            if (MIXED) {
+                uint32_t o0[kRtpHalfLoads], o1[kRtpHalfLoads];
+                offsets(__ballot(cur_radio != 0u), o0, o1);
+#pragma unroll
+                for (int j = 0; j < kRtpHalfLoads; ++j) X[j] = ld(b0, o0[j]);
+#pragma unroll
+                for (int j = 0; j < kRtpHalfLoads; ++j) Y[j] = ld(b0, o1[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kRtpHalfLoads; ++j) X[j] = ld(b0, roff0[j]);
+#pragma unroll
+                for (int j = 0; j < kRtpHalfLoads; ++j) Y[j] = ld(b0, roff1[j]);
+            }
+        }
+        uint32_t s_next = grab();
+        for (;;) {
+            const bool has_next = s_next < n_super;
+            const uint32_t s_load = has_next ? s_next : 0u;
+            const uint32_t f0 = sidx * kSuperFrames;
+            const bool my_alaw = cur_pt == IGDSP_PT_PCMA;
+            const uint64_t amask = __ballot(my_alaw);
+            const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
+            const uint8_t *nbase = slots + (uint64_t)s_load * super_bytes;
+            const uint32_t nxt_pt = fetch_pt(s_load);
+            const uint32_t nxt_radio = fetch_radio(s_load);
+            const uint32_t hbytes = SLOT ? 20u : (MIXED ? (cur_radio != 0u ? 20u : 12u) : hdr);   // of this lane's own packet
+            const uint32_t full = hbytes + (uint32_t)kFrame;
+            uint32_t my_size = full;
+            if (!SLOT && sizes != nullptr) my_size = sizes[f0 + lane];
+            if (MIXED) {
+                const uint64_t nrm = __ballot(nxt_radio != 0u);
+                rtp_half<SLOT, true>(lds, strip, X, am_lo, fr, pm, hs, off, lane, nbase, roff0, (uint32_t)nrm);
+                rtp_half<SLOT, true>(lds, strip + kRtpStrip / 2, Y, am_hi, fr, pm, hs, off, lane, nbase, roff1, (uint32_t)(nrm >> 32));
+            } else {
+                rtp_half<SLOT>(lds, strip, X, am_lo, fr, pm, hs, off, lane, nbase, roff0);
+                rtp_half<SLOT>(lds, strip + kRtpStrip / 2, Y, am_hi, fr, pm, hs, off, lane, nbase, roff1);
+            }
+            const uint32_t s_after = has_next ? grab() : 0xFFFFFFFFu;   // its LDS round trip hides under the fold below
+            wave_lds_fence();
+            {
+                const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kSlotPieces);   // 96-byte rows
+                const uint4 h = row[0];                   // {size word | 0, RTP bytes 0-3, ext profile/length, ED-137 word}
+                uint64_t s = 0;
+                uint32_t peak = 0, bsum = 0, fail = 0;
+#pragma unroll
+                for (int i = 1; i < kSlotPieces / 2; ++i) {
+                    const uint4 v = row[i];
+                    s += (uint64_t)(v.x + v.z);
+                    peak = max(max(peak, v.y & 0x7FFFu), v.w & 0x7FFFu);
+                    bsum += ((v.y >> 16) & 0x7FFFu) + ((v.w >> 16) & 0x7FFFu);
+                    fail |= v.y | v.w;
+                }
+                // header: same rules as parse_rtp()
+                const uint32_t size = SLOT ? (h.x & 0xFFFFu) : my_size, w0 = h.y, pt = (w0 >> 8) & 0x7Fu;
+                uint32_t hf = (((w0 >> 6) & 3u) == 2u ? IGDSP_RTP_V2 : 0u) | ((w0 & 0x10u) ? IGDSP_RTP_X : 0u) |
+                              ((w0 & 0x8000u) ? IGDSP_RTP_MARKER : 0u);
+                uint32_t ed = 0, plen = 0;
+                if (size < hbytes) hf = IGDSP_RTP_RUNT;
+                else {
+                    plen = size - hbytes;
+                    if (hbytes == 20u) {
+                        if (pt == 8u || pt == 0u || pt == 18u || pt == 123u) ed = __builtin_bswap32(h.w);
+                        if ((w0 & 0x10u) && h.z == 0x01006701u) hf |= IGDSP_RTP_ED137_OK;
+                    }
+                    if (pt == 123u) hf |= IGDSP_RTP_KEEPALIVE;
+                    if (plen > (uint32_t)kFrame) hf |= IGDSP_RTP_OVERSIZE;
+                    else if ((pt == 0u || pt == 8u) && plen > 0u) hf |= IGDSP_RTP_METERED;
+                }
+                const bool pt_ok = pt == cur_pt && (pt == 0u || pt == 8u);
+                const bool whole = size == full && pt_ok;
+                const bool shortp = pt_ok && size > hbytes && size < full;           // 0 < payloadlen < 160
+                const bool metered = whole || shortp;
+                const uint32_t fi = f0 + lane;
+                if (info != nullptr) {
+                    uint2 rec;
+                    rec.x = ed;
+                    rec.y = (size < hbytes ? 0u : plen) | ((size >= 2u ? pt : 0u) << 16) | (hf << 24);
+                    *reinterpret_cast<uint2 *>(info + fi) = rec;
+                }
+                uint32_t bm = 0, fl = 0;
+                uint4 rec = make_uint4(0u, 0u, 0u, (uint32_t)IGDSP_FLAG_EMPTY << 24);
+                if (whole) rec = pack_stats160(s, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl);
+                if (__ballot(shortp) != 0ull) {           // wave-uniform, rare: see meter_short
+                    if (shortp) {
+                        const uint8_t *pp = slots + (uint64_t)sidx * super_bytes + lane * (SLOT ? (uint32_t)IGDSP_SLOT_BYTES : stride) +
+                                            (SLOT ? (uint32_t)IGDSP_SLOT_PAYLOAD_OFFSET : hbytes);
+                        bool pr;
+                        meter_short(lds, off, pp, plen, my_alaw, s, peak, bsum, pr);
+                        rec = pack_stats(s << 4, peak, bsum, plen, my_alaw, pr, bm, fl);
+                    }
+                }
+                st_stream(reinterpret_cast<uint4 *>(stats + fi), rec);
+                if (AGG) {
+                    if (metered) { a_sumsq += s << 4; a_samp += whole ? (uint32_t)kFrame : plen; a_bm += bm; a_peak = max(a_peak, peak); }
+                    u_frames += (uint32_t)__builtin_popcountll(__ballot(metered));
+                    u_sil += (uint32_t)__builtin_popcountll(__ballot(metered && (fl & IGDSP_FLAG_SILENT) != 0u));
+                    u_clip += (uint32_t)__builtin_popcountll(__ballot(metered && (fl & IGDSP_FLAG_CLIPPED) != 0u));
+                }
+            }
+            wave_lds_fence();
+            if (!has_next) break;
+            sidx = s_next;
+            s_next = s_after;
+            cur_pt = nxt_pt;
+            cur_radio = nxt_radio;
+        }
+    }
+    bq_finish(gqueue, G);
+    if (AGG && agg != nullptr) {
+        const bool l0 = lane == 0u;               // the wave-uniform counts enter the wave reduction once, through lane 0
+        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kRtpWaves, a_sumsq, (uint64_t)a_samp, l0 ? u_frames : 0u,
+                         l0 ? u_sil : 0u, l0 ? u_clip : 0u, a_bm, a_peak);
+    }
+}
+
+// ============================================================================
+// SURVEY 8(f) rank 1 — ED-137 RTP depayload + gather (transport_rtp_cb's header parse and payload
+// copy, TransportAdapter.cpp:240-292, batched).  One lane per 16-byte piece of the DENSE output:
+// writes are full coalesced dwordx4; reads come from pkt + header (4-byte aligned: header 12 or 20,
+// slot stride % 4 == 0) as four dwords.  Lane q == 0 of a frame also parses the header and emits
+// len / info.  Needs n % 16 == 0; other n use the byte kernel below.
+// ============================================================================
+struct FrameHdr { uint32_t len; igdsp_rtp_info info; };
+
+__device__ __forceinline__ FrameHdr parse_rtp_words(uint32_t w0, uint32_t w3, uint32_t w4, uint32_t size, uint32_t hdr, bool radio, uint32_t n)
+{
+    // w0 = packet bytes 0-3, w3 = bytes 12-15 (extension profile / length), w4 = bytes 16-19 (ED-137 word); w3 / w4 are
+    // only looked at for radio packets of at least 20 bytes
+    FrameHdr r;
+    r.len = 0; r.info.ed137 = 0; r.info.payload_len = 0; r.info.pt = 0; r.info.flags = 0;
+    if (size < hdr) {
+        r.info.flags = IGDSP_RTP_RUNT;
+        if (size >= 2u) r.info.pt = (uint8_t)((w0 >> 8) & 0x7Fu);
+        return r;
+    }
+    const uint32_t pt = (w0 >> 8) & 0x7Fu;
+    uint32_t fl = (((w0 >> 6) & 3u) == 2u ? IGDSP_RTP_V2 : 0u) | ((w0 & 0x10u) ? IGDSP_RTP_X : 0u) | ((w0 & 0x8000u) ? IGDSP_RTP_MARKER : 0u);
+    if (radio) {
+        if (pt == 8u || pt == 0u || pt == 18u || pt == 123u) r.info.ed137 = __builtin_bswap32(w4);   // ntohl
+        if ((w0 & 0x10u) && w3 == 0x01006701u) fl |= IGDSP_RTP_ED137_OK;                               // bytes 01 67 00 01
+    }
+    if (pt == 123u) fl |= IGDSP_RTP_KEEPALIVE;
+    const uint32_t pl = size - hdr;
+    if (pl > n) fl |= IGDSP_RTP_OVERSIZE;
+    else if ((pt == 0u || pt == 8u) && pl > 0u) { fl |= IGDSP_RTP_METERED; r.len = pl; }
+    r.info.pt = (uint8_t)pt; r.info.payload_len = (uint16_t)pl; r.info.flags = (uint8_t)fl;
+    return r;
+}
+
+__device__ __forceinline__ FrameHdr parse_rtp(const uint8_t *pkt, uint32_t size, uint32_t hdr, bool radio, uint32_t n)
+{
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(pkt);
+    const bool wide = radio && size >= hdr;
+    return parse_rtp_words(w[0], wide ? w[3] : 0u, wide ? w[4] : 0u, size, hdr, radio, n);
+}
+
+// Tuned n == 160 form: a wave takes 64 consecutive packets.  Twelve dword-aligned 16-byte pieces per packet (bytes
+// [0,16) and [4,20) of the header, then the ten payload pieces at hdr + 16 k) are spread over the lanes exactly as in
+// k_meter_rtp64, so every load instruction covers ~5 whole packets.  The header pieces hand {bytes 0-3, ext word,
+// ED-137 word} to the packet's frame lane through LDS; the frame lane parses once per packet (instead of once per
+// piece), writes len / info coalesced and publishes the payload length; each payload piece then masks and stores
+// itself into the dense output (one contiguous run per store instruction).
+constexpr int kDpWaves = 4;
+__global__ __launch_bounds__(kDpWaves * 64, 3) void k_depayload64(const uint8_t *__restrict__ packets, const uint16_t *__restrict__ sizes,
+                                                               const uint8_t *__restrict__ radio, uint32_t C, uint32_t n_frames,
+                                                               uint32_t stride, uint8_t *__restrict__ payload,
+                                                               uint16_t *__restrict__ len, igdsp_rtp_info *__restrict__ info)
+{
+    __shared__ uint4 hdrs[kDpWaves][64];          // per packet {bytes 0-3, -, ext word, ED-137 word}; .y reused for the parsed length
+    __shared__ uint4 xp[kDpWaves][kSuperFrames * kPiecesPerFrame];   // 10 KiB per wave: the dense output block, for whole-line stores
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint4 *hw = hdrs[wave];
+    const uint32_t n_super = n_frames / kSuperFrames;
+    const uint32_t total_waves = gridDim.x * kDpWaves;
+    for (uint32_t sidx = blockIdx.x * kDpWaves + wave; sidx < n_super; sidx += total_waves) {
+        // piece p = j * 64 + lane of the item -> packet fr = p / 12, piece q = p % 12.  Recomputed from an opaque copy of
+        // the lane id in each phase: hoisting all 12 x 3 sets of lane constants out of the loop costs more registers
+        // (and spills) than the few VALU ops they take.
+        uint32_t ln = lane;
+        asm volatile("" : "+v"(ln));
+        const uint32_t f0 = sidx * kSuperFrames, fi = f0 + lane;
+        const bool my_radio = radio[fi % C] != 0;
+        const uint32_t my_size = min(sizes ? (uint32_t)sizes[fi] : stride, stride);
+        const uint64_t rmask = __ballot(my_radio);
+        const uint8_t *base = packets + (uint64_t)f0 * stride;                       // wave-uniform bases, 32-bit lane offsets
+        uint4 *ob = reinterpret_cast<uint4 *>(payload) + (uint64_t)f0 * kPiecesPerFrame;
+        uint4 d[kSlotPieces];
+#pragma unroll
+        for (int j = 0; j < kSlotPieces; ++j) {
+            const uint32_t p = (uint32_t)j * 64u + ln, fr = p / 12u, q = p - fr * 12u;
+            const uint32_t hb = (uint32_t)((rmask >> fr) & 1ull);
+            const uint32_t po = q == 0u ? 0u : (q == 1u ? 4u : 12u + 8u * hb + 16u * (q - 2u));
+            d[j] = ld16_dw(base + (fr * stride + po));
+        }
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int j = 0; j < kSlotPieces; ++j) {
+            const uint32_t p = (uint32_t)j * 64u + ln, fr = p / 12u, q = p - fr * 12u;
+            if (q < 2u)                              // piece 0 -> {.x = bytes 0-3, .y = 0}; piece 1 -> {.z = ext word, .w = ED-137 word}
+                reinterpret_cast<uint2 *>(&hw[fr])[q] = q == 0u ? make_uint2(d[j].x, 0u) : make_uint2(d[j].z, d[j].w);
+        }
+        wave_lds_fence();
+        {
+            const uint4 h = hw[lane];
+            const FrameHdr r = parse_rtp_words(h.x, h.z, h.w, my_size, my_radio ? 20u : 12u, my_radio, (uint32_t)kFrame);
+            len[fi] = (uint16_t)r.len;
+            info[fi] = r.info;
+            hw[lane].y = r.len;
+        }
+        wave_lds_fence();
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int j = 0; j < kSlotPieces; ++j) {
+            const uint32_t p = (uint32_t)j * 64u + ln, fr = p / 12u, q = p - fr * 12u;
+            if (q >= 2u) {
+                const uint32_t flen = hw[fr].y, b0 = 16u * (q - 2u);
+                const uint32_t nb = flen > b0 ? min(flen - b0, 16u) : 0u;
+                uint32_t x[4] = {d[j].x, d[j].y, d[j].z, d[j].w};
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {  // keep the first nb bytes of the piece, branch-free
+                    const uint32_t bits = 8u * (nb > 4u * k ? min(nb - 4u * k, 4u) : 0u);
+                    x[k] &= (uint32_t)((1ull << bits) - 1ull);
+                }
+                xp[wave][fr * (uint32_t)kPiecesPerFrame + (q - 2u)] = make_uint4(x[0], x[1], x[2], x[3]);
+            }
+        }
+        wave_lds_fence();
+        // the block is complete in LDS in output order: ten stores of 1 KiB of whole lines each
+#pragma unroll
+        for (int j = 0; j < kPiecesPerFrame; ++j) ob[(uint32_t)j * 64u + lane] = xp[wave][(uint32_t)j * 64u + lane];
+        wave_lds_fence();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_depayload16(const uint8_t *__restrict__ packets, const uint16_t *__restrict__ sizes,
+                                                     const uint8_t *__restrict__ radio, uint32_t C, uint32_t n_frames,
+                                                     uint32_t stride, uint32_t n, uint8_t *__restrict__ payload,
+                                                     uint16_t *__restrict__ len, igdsp_rtp_info *__restrict__ info)
+{
+    const uint32_t ppf = n >> 4;                                   // pieces per frame
+    const uint64_t n_pieces = (uint64_t)n_frames * ppf;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pieces; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t fi = (uint32_t)(p / ppf), q = (uint32_t)(p - (uint64_t)fi * ppf);
+        const uint32_t c = fi % C;
+        const bool rad = radio[c] != 0;
+        const uint32_t hdr = rad ? 20u : 12u;
+        const uint8_t *pkt = packets + (uint64_t)fi * stride;
+        const uint32_t size = min(sizes ? (uint32_t)sizes[fi] : stride, stride);
+        const FrameHdr h = parse_rtp(pkt, size, hdr, rad, n);
+        if (q == 0u) { len[fi] = (uint16_t)h.len; info[fi] = h.info; }
+        const uint32_t b0 = q * 16u;
+        uint32_t v[4] = {0u, 0u, 0u, 0u};
+        if (h.len > b0) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(pkt + hdr + b0);
+            const uint32_t nb = min(h.len - b0, 16u);
+            if (hdr + b0 + 16u <= stride) {
+                // whole piece inside the slot: ONE 16-byte load at dword alignment (gfx950 global loads need only
+                // dword alignment for dwordx4) instead of four dword loads, then mask what lies past the length
+                struct __attribute__((packed, aligned(4))) Q { uint32_t a, b, c, d; };
+                const Q qv = *reinterpret_cast<const Q *>(src);
+                const uint32_t x[4] = {qv.a, qv.b, qv.c, qv.d};
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const uint32_t keep = nb > 4u * k ? min(nb - 4u * k, 4u) : 0u;
+                    v[k] = keep == 4u ? x[k] : (keep == 0u ? 0u : (x[k] & ((1u << (8u * keep)) - 1u)));
+                }
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k)
+                    if (nb > 4u * k) {                              // the dword may extend past the packet's size but never past its slot
+                        uint32_t x = (hdr + b0 + 4u * k + 4u <= stride) ? src[k] : 0u;
+                        const uint32_t keep = nb - 4u * k;
+                        if (keep < 4u) x &= (1u << (8u * keep)) - 1u;
+                        v[k] = x;
+                    }
+            }
+        }
+        reinterpret_cast<uint4 *>(payload)[p] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_depayload_bytes(const uint8_t *__restrict__ packets, const uint16_t *__restrict__ sizes,
+                                                         const uint8_t *__restrict__ radio, uint32_t C, uint32_t n_frames,
+                                                         uint32_t stride, uint32_t n, uint8_t *__restrict__ payload,
+                                                         uint16_t *__restrict__ len, igdsp_rtp_info *__restrict__ info)
+{
+    // one wavefront per frame, any n and any (4-byte aligned) stride
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t fi = blockIdx.x * 4u + wave; fi < n_frames; fi += gridDim.x * 4u) {
+        const uint32_t c = fi % C;
+        const bool rad = radio[c] != 0;
+        const uint32_t hdr = rad ? 20u : 12u;
+        const uint8_t *pkt = packets + (uint64_t)fi * stride;
+        const uint32_t size = min(sizes ? (uint32_t)sizes[fi] : stride, stride);
+        const FrameHdr h = parse_rtp(pkt, size, hdr, rad, n);
+        if (lane == 0u) { len[fi] = (uint16_t)h.len; info[fi] = h.info; }
+        for (uint32_t i = lane; i < n; i += 64u) payload[(uint64_t)fi * n + i] = (i < h.len) ? pkt[hdr + i] : (uint8_t)0;
+    }
+}
+
+hipError_t launch_decode_meter_rtp(const LaunchCfg &cfg, const uint8_t *slots, const uint16_t *sizes, const uint8_t *codec, uint32_t C,
+                                   uint32_t F, uint32_t stride, uint32_t hdr, igdsp_frame_stats *stats, igdsp_rtp_info *info,
+                                   igdsp_aggregate *agg, uint32_t rank, hipStream_t s, const uint8_t *radio)
+{
+    // stride == 0: the 192-byte slot format; otherwise packets packed at `stride` with a `hdr`-byte RTP header, or, with
+    // `radio`, a per-channel 20 / 12-byte header
+    const uint32_t n_frames = C * F;                       // caller guarantees a multiple of 64
+    if (n_frames == 0) return hipSuccess;
+    const uint32_t grid = blocks_for(n_frames / kSuperFrames, kRtpWaves, (uint32_t)cfg.compute_units);
+    const dim3 blk(kRtpWaves * 64);
+    if (stride == 0) {
+        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, cfg.gqueue, radio);
+        else     hipLaunchKernelGGL((k_meter_rtp64<false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, cfg.gqueue, radio);
+    } else if (radio != nullptr) {
+        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, cfg.gqueue, radio);
+        else     hipLaunchKernelGGL((k_meter_rtp64<false, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, cfg.gqueue, radio);
+    } else {
+        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, cfg.gqueue, radio);
+        else     hipLaunchKernelGGL((k_meter_rtp64<false, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, cfg.gqueue, radio);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_depayload(const LaunchCfg &cfg, const uint8_t *packets, const uint16_t *sizes, const uint8_t *radio,
+                            uint32_t C, uint32_t F, uint32_t stride, uint32_t n, uint8_t *payload, uint16_t *len,
+                            igdsp_rtp_info *info, hipStream_t s)
+{
+    const uint32_t n_frames = C * F;
+    if (n_frames == 0) return hipSuccess;
+    const uint32_t cap = (uint32_t)cfg.compute_units * 8u;
+    const bool aligned = (reinterpret_cast<uintptr_t>(payload) & 15u) == 0u;
+    if (aligned && n == (uint32_t)kFrame && (n_frames % kSuperFrames) == 0u && stride >= 180u) {
+        // whole super-chunks of n == 160 packets whose slots hold a full radio packet: header parsed once per packet
+        hipLaunchKernelGGL(k_depayload64, dim3(blocks_for(n_frames / kSuperFrames, kDpWaves, cap)), dim3(kDpWaves * 64), 0, s,
+                           packets, sizes, radio, C, n_frames, stride, payload, len, info);
+    } else if ((n & 15u) == 0u && aligned) {
+        const uint64_t pieces = (uint64_t)n_frames * (n >> 4);
+        hipLaunchKernelGGL(k_depayload16, dim3(blocks_for(pieces, 256, cap)), dim3(256), 0, s, packets, sizes, radio, C, n_frames, stride, n, payload, len, info);
+    } else {
+        hipLaunchKernelGGL(k_depayload_bytes, dim3(blocks_for(n_frames, 4, cap)), dim3(256), 0, s, packets, sizes, radio, C, n_frames, stride, n, payload, len, info);
+    }
+    return hipGetLastError();
+}
+
+
+}  // namespace igdsp

@@ -19,8 +19,8 @@ def resources():
     from igate4xsoftphonedsp_amd import build as b
     import kernel_resources as kr
 
-    srcs = [os.path.join(b.CSRC, s) for s in b.DEVICE_SOURCES] + [os.path.join(b.CSRC, "igdsp_internal.h")]
-    if not os.path.exists(kr.ASM) or any(os.path.getmtime(s) > os.path.getmtime(kr.ASM) for s in srcs):
+    srcs = [os.path.join(b.CSRC, s) for s in b.DEVICE_SOURCES] + [os.path.join(b.CSRC, h) for h in ("igdsp_internal.h", "igdsp_device.h")]
+    if len(kr.asm_files()) < 4 or any(os.path.getmtime(s) > min(os.path.getmtime(a) for a in kr.asm_files()) for s in srcs):
         b.build(save_asm=True)
     return kr.resources()
 

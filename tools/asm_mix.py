@@ -5,12 +5,17 @@ import collections
 import re
 import sys
 
-ASM = "igate4xsoftphonedsp_amd/_asm/igdsp_kernels-hip-amdgcn-amd-amdhsa-gfx950.s"
+import glob
+
+ASMS = sorted(glob.glob("igate4xsoftphonedsp_amd/_asm/igdsp_k_*-hip-amdgcn-amd-amdhsa-gfx950.s"))
 
 
 def main():
     key = sys.argv[1]
-    lines = open(ASM).read().split("\n")
+    for path in ASMS:                                 # the translation unit that defines the kernel
+        lines = open(path).read().split("\n")
+        if any(re.match(r"^_Z\w*:", l) and key in l for l in lines):
+            break
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*:", l) and key in l)
     end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
     body = lines[start + 1:end]

@@ -2,9 +2,23 @@
 """Per-kernel register / scratch / LDS use from the saved ISA (python -m igate4xsoftphonedsp_amd.build --asm)."""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ASM = os.path.join(ROOT, "igate4xsoftphonedsp_amd", "_asm", "igdsp_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
+ASM_DIR = os.path.join(ROOT, "igate4xsoftphonedsp_amd", "_asm")
+ASM = os.path.join(ASM_DIR, "igdsp_k_meter-hip-amdgcn-amd-amdhsa-gfx950.s")      # one of the translation units: staleness check
 
-def resources(path=ASM):
+
+def asm_files():
+    import glob
+    return sorted(glob.glob(os.path.join(ASM_DIR, "igdsp_k_*-hip-amdgcn-amd-amdhsa-gfx950.s")))
+
+
+def resources(paths=None):
+    out = []
+    for path in (paths or asm_files()):
+        out += _resources_of(path)
+    return out
+
+
+def _resources_of(path):
     s = open(path).read()
     meta = s[s.index("amdhsa.kernels:"):]
     out = []
@@ -15,6 +29,7 @@ def resources(path=ASM):
     names = subprocess.run(["c++filt"] + [r["name"] for r in out], capture_output=True, text=True).stdout.split("\n")
     for r, d in zip(out, names):
         r["demangled"] = d.split("(")[0]
+        r["file"] = os.path.basename(path).split("-")[0]
     return out
 
 if __name__ == "__main__":
