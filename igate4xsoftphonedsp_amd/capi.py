@@ -16,7 +16,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libigdsp.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 PT_PCMU, PT_PCMA, PT_R2S = 0, 8, 123
 SAMPLES_PER_FRAME = 160
 MAX_PAYLOAD = 256

@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define IGDSP_ABI_VERSION 1
+/* 2: igdsp_io_alloc / igdsp_io_free, igdsp_wav_expand, staging ring (igdsp_level.dropped, IGDSP_STAGE_DEPTH); every round-1 entry is
+ * unchanged in signature and meaning. */
+#define IGDSP_ABI_VERSION 2
 
 /* ---- error codes (0 == PJ_SUCCESS-style success) ------------------------- */
 #define IGDSP_OK          0

@@ -29,7 +29,7 @@ def test_header_symbols_all_exported_and_bound(lib):
     raw = ctypes.CDLL(capi.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.igdsp_abi_version() == capi.ABI_VERSION == 1
+    assert lib.igdsp_abi_version() == capi.ABI_VERSION == 2
 
 
 def test_struct_layouts_agree(orc):
