@@ -692,7 +692,7 @@ __global__ __launch_bounds__(kImgMaxWaves * 64) void k_meter_image(
 // ============================================================================
 // STORE: the decoded int16 PCM goes out as well (pcm[F][C][n], dword aligned): every payload piece stores its 32 bytes as two
 // dword-aligned 16-byte stores, the tail piece the 8 T bytes of the frame's tail samples; 12 waves (eight more live registers).
-template <int QP, bool STORE = false> struct StridedGeom { static constexpr int kWaves = (QP <= 11 && !STORE) ? 16 : 12; };
+template <int QP, bool STORE = false> struct StridedGeom { static constexpr int kWaves = STORE ? (QP <= 2 ? 16 : (QP <= 11 ? 12 : 10)) : (QP <= 11 ? 16 : 12); };
 
 template <int Q, bool TAIL, bool AGG, bool STORE = false>
 __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 64)) void k_meter_strided(
@@ -703,7 +703,7 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
     constexpr int QP = Q + (TAIL ? 1 : 0);                       // pieces per frame
     constexpr int kWaves = StridedGeom<QP, STORE>::kWaves;
     constexpr int kStrip = kSuperFrames * QP;
-    __shared__ uint2 lds[kLutEntries + kWaves * kStrip];
+    __shared__ uint2 lds[kLutEntries + kWaves * kStrip + (STORE ? kWaves * 256 : 0)];   // LUT, strips (+ 2 KiB PCM transposition scratch per wave)
     __shared__ BlockQueue<kWaves> bq;
     uint32_t gb1 = 0;
     if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);
@@ -713,6 +713,7 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
 
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint2 *strip = lds + kLutEntries + wave * kStrip;
+    uint8_t *xpose = STORE ? reinterpret_cast<uint8_t *>(lds + kLutEntries + kWaves * kStrip + wave * 256) : nullptr;
     const uint32_t off = (lane & 31u) * 8u;
     const uint32_t T = (n - 16u * Q) >> 2;                       // tail dwords per frame (TAIL: 1 or 2), wave-uniform
     // per-lane piece constants, two pieces per register: frame of the item (6 bits) | probe shift << 8 (24 = none) | tail
@@ -742,9 +743,12 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
     uint32_t a_bm = 0, a_peak = 0;
     uint32_t u_frames = 0, u_sil = 0, u_clip = 0;
     auto fetch_pt = [&](uint32_t sidx) { return (uint32_t)codec[(sidx * (uint32_t)kSuperFrames + lane) % C]; };
-    auto grab = [&]() { return bq_grab(bq, gqueue, G, lane, 0u); };
+    // with a bulk output (PCM) the two halves of the batch range are visited alternately, as in k_meter_chunk64: igdsp_io_alloc
+    // spreads a bulk buffer's halves over two memory classes and the writes should reach both at any moment
+    const uint32_t n_batches = STORE ? (n_super + (uint32_t)kWaves - 1u) / (uint32_t)kWaves : 0u;
+    auto grab = [&]() { return bq_grab(bq, gqueue, G, lane, n_batches); };
 
-    uint32_t sidx = blockIdx.x * (uint32_t)kWaves + wave;
+    uint32_t sidx = spread_batch(blockIdx.x, n_batches) * (uint32_t)kWaves + wave;
     if (sidx < n_super) {
         uint4 d[QP];
         uint32_t cur_pt = fetch_pt(sidx);
@@ -804,20 +808,36 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
                         if (tail_of(j)) ent = make_uint2(d[j].z, d[j].w);       // the frame's last two dwords, raw
                         strip[j * 64 + lane] = ent;
                         if (STORE) {
-                            // 16 samples = 32 bytes at twice the payload offset.  The tail piece's last T dwords are the frame's tail:
-                            // their 8 T bytes of PCM go right behind the 32 bytes of the previous lane (piece Q - 1 of the same
-                            // frame), so the wave's stores stay one contiguous run per frame.
-                            u32x4_a4_t v0, v1;
-                            v0.x = o[0]; v0.y = o[1]; v0.z = o[2]; v0.w = o[3]; v1.x = o[4]; v1.y = o[5]; v1.z = o[6]; v1.w = o[7];
-                            if (!tail_of(j)) {
-                                uint8_t *op = reinterpret_cast<uint8_t *>(pcm) + 2ull * ((uint64_t)sidx * item_bytes + po_of(j));
-                                reinterpret_cast<u32x4_a4_t *>(op)[0] = v0;
-                                reinterpret_cast<u32x4_a4_t *>(op)[1] = v1;
+                            // The wave's PCM for row j is ONE contiguous run: piece p = 64 j + lane puts its 32 bytes (the tail piece:
+                            // the 8 T bytes of the frame's tail samples) at S(p) = 2 n f + 32 q of the item's PCM, and S grows by
+                            // exactly the previous piece's length from lane to lane.  Lanes park their bytes at S - S(lane 0) in a
+                            // per-wave 2 KiB LDS scratch and read the run back 16 bytes per lane, so each store instruction writes
+                            // 1 KiB contiguous instead of 16-byte pieces at 32-byte stride (0.58 -> see DESIGN 3.2b at n = 164).
+                            const bool tl = tail_of(j);
+                            const uint32_t fj = fr_of(j), qj = (uint32_t)j * 64u + lane - fj * (uint32_t)QP;
+                            const uint32_t S = fj * 2u * n + (tl ? 32u * (uint32_t)Q : 32u * qj);
+                            const uint32_t R = (uint32_t)__builtin_amdgcn_readfirstlane((int)S);
+                            const uint32_t L = TAIL ? (uint32_t)__builtin_amdgcn_readlane((int)(S + (tl ? 8u * T : 32u)), 63) - R : 2048u;
+                            uint2 *xp = reinterpret_cast<uint2 *>(xpose + (S - R));
+                            if (!tl) {
+                                xp[0] = make_uint2(o[0], o[1]); xp[1] = make_uint2(o[2], o[3]);
+                                xp[2] = make_uint2(o[4], o[5]); xp[3] = make_uint2(o[6], o[7]);
+                            } else if (T == 2u) {
+                                xp[0] = make_uint2(o[4], o[5]); xp[1] = make_uint2(o[6], o[7]);
                             } else {
-                                uint8_t *op = reinterpret_cast<uint8_t *>(pcm) + 2ull * ((uint64_t)sidx * item_bytes + fr_of(j) * n + 16u * Q);
-                                if (T == 2u) reinterpret_cast<u32x4_a4_t *>(op)[0] = v1;
-                                else { reinterpret_cast<uint32_t *>(op)[0] = o[6]; reinterpret_cast<uint32_t *>(op)[1] = o[7]; }
+                                xp[0] = make_uint2(o[6], o[7]);
                             }
+                            wave_lds_fence();
+                            const uint4 r0 = reinterpret_cast<const uint4 *>(xpose)[lane], r1 = reinterpret_cast<const uint4 *>(xpose)[64u + lane];
+                            wave_lds_fence();
+                            uint8_t *ob = reinterpret_cast<uint8_t *>(pcm) + 2ull * ((uint64_t)sidx * item_bytes) + R;
+                            u32x4_a4_t v0, v1;
+                            v0.x = r0.x; v0.y = r0.y; v0.z = r0.z; v0.w = r0.w; v1.x = r1.x; v1.y = r1.y; v1.z = r1.z; v1.w = r1.w;
+                            const uint32_t c0 = 16u * lane, c1 = 1024u + 16u * lane;
+                            if (!TAIL || c0 + 16u <= L) *reinterpret_cast<u32x4_a4_t *>(ob + c0) = v0;
+                            else if (c0 < L) { reinterpret_cast<uint32_t *>(ob + c0)[0] = r0.x; reinterpret_cast<uint32_t *>(ob + c0)[1] = r0.y; }
+                            if (!TAIL || c1 + 16u <= L) *reinterpret_cast<u32x4_a4_t *>(ob + c1) = v1;
+                            else if (c1 < L) { reinterpret_cast<uint32_t *>(ob + c1)[0] = r1.x; reinterpret_cast<uint32_t *>(ob + c1)[1] = r1.y; }
                         }
                         d[j] = ld16_dw(nbase + po_of(j));
                         sum = 0; peak = 0; bsum = 0;
