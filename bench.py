@@ -55,8 +55,9 @@ def parse():
     ap.add_argument("--channels", type=int, default=65536, help="channels PER GPU")
     ap.add_argument("--frames", type=int, default=128)
     ap.add_argument("--frame-bytes", type=int, default=160,
-                    help="meter / store modes only: bytes (= samples) per frame; 160 is the 20 ms frame of the headline, other multiples of 4 "
-                         "(24, 80, 164, 240 ...) run the LDS-image kernel")
+                    help="meter / store / roundtrip modes: bytes (= samples) per frame; 160 is the 20 ms frame of the headline, the reference's "
+                         "other sizes (24, 80, 164, 168, 240) run k_meter_strided / k_roundtrip_strided, other multiples of 4 the "
+                         "LDS-image kernel")
     ap.add_argument("--total-channels", type=int, default=0,
                     help="strong scaling: this many channels in total, split evenly over the ranks (SURVEY 8d: 524288 over 1/2/4/8 "
                          "GPUs); overrides --channels and reports \"scaling\": \"strong\"")
@@ -332,6 +333,8 @@ def main():
         OUT = P
     else:
         OUT = BufSet("abi")
+        if os.environ.get("IGDSP_BENCH_SETTLE_S"):      # experiment: idle time between the buffer set-up and the first launch
+            torch.cuda.synchronize(); time.sleep(float(os.environ["IGDSP_BENCH_SETTLE_S"]))
 
     def step(i: int, coll: bool = True):
         agg = agg_ring[i] if coll else scratch_agg   # the comparison pass of --force-collective must not add into the ring again
@@ -471,7 +474,7 @@ def main():
     if os.path.exists(traffic_file):
         try:
             with open(traffic_file) as fh:
-                tr = json.load(fh).get(args.mode)
+                tr = json.load(fh).get(args.mode + (str(args.frame_bytes) if args.frame_bytes != N_SAMPLES else ""))
             if tr and tr.get("kernel") == kernel_name and tr.get("channels") == C_ and tr.get("frames") == F_:
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = tr.get("source")

@@ -66,7 +66,7 @@ class IoBuf(C.Structure):
 class IoReport(C.Structure):
     _fields_ = [("placed", C.c_uint32), ("bulk_spread", C.c_uint32), ("classes_found", C.c_uint32), ("chunks_explored", C.c_uint32),
                 ("probes", C.c_uint32), ("reseeds", C.c_uint32), ("chunk_bytes", C.c_uint64), ("explored_bytes", C.c_uint64),
-                ("probe_ms_same", C.c_float), ("probe_ms_other", C.c_float), ("setup_ms", C.c_float), ("reserved2", C.c_float)]
+                ("probe_ms_same", C.c_float), ("probe_ms_other", C.c_float), ("setup_ms", C.c_float), ("settle_ms", C.c_float)]
 
     def as_dict(self):
         return {k: (round(getattr(self, k), 4) if isinstance(getattr(self, k), float) else getattr(self, k))

@@ -201,6 +201,69 @@ __device__ __forceinline__ uint32_t wave_reduce_dpp(uint32_t v, Op op)
 struct OpAdd { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
 struct OpMax { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return max(a, b); } };
 
+// Barrier-free launch-aggregate commit for the persistent kernels: a wave that has run out of work reduces its partials with DPP (no LDS, no shuffle tree), lane 0 adds the
+// wave totals into a 48-byte block accumulator with seven LDS atomics and bumps a counter; the
+// wave that finds the counter at nwaves - 1 moves the block totals to the aggregate with device atomics.  No wave waits for
+// another, so the kernel's tail is one LDS round trip instead of two barriers and two shuffle trees (agg_commit_block):
+// measured on k_meter_chunk64, 0.2314 -> 0.2294 ms per launch (the kernel without any aggregate: 0.2281).
+struct AggBlock { unsigned long long sumsq, samples; uint32_t frames, n_silent, n_clipped, bm_sum, peak, done; };
+
+__device__ __forceinline__ void agg_block_init(AggBlock &b)      // one thread, before a barrier every wave passes
+{
+    b.sumsq = 0; b.samples = 0; b.frames = 0; b.n_silent = 0; b.n_clipped = 0; b.bm_sum = 0; b.peak = 0; b.done = 0;
+}
+
+// sumsq / bm_sum / peak: per lane.  samples / frames / n_silent / n_clipped: wave-uniform (lane 0 adds them).
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)      // 24-bit limbs: 64 of them fit 32 bits
+{
+    const uint32_t s0 = wave_reduce_dpp((uint32_t)v & 0xFFFFFFu, OpAdd{});
+    const uint32_t s1 = wave_reduce_dpp((uint32_t)(v >> 24) & 0xFFFFFFu, OpAdd{});
+    const uint32_t s2 = wave_reduce_dpp((uint32_t)(v >> 48), OpAdd{});
+    return (uint64_t)s0 + ((uint64_t)s1 << 24) + ((uint64_t)s2 << 48);
+}
+
+// sumsq / samples / bm_sum / peak: per lane.  frames / n_silent / n_clipped: wave-uniform.  When the block's last wave is
+// out, the last BLOCK out re-arms the device work queue gq (nullptr: static schedule) for the next launch.
+// agg == nullptr: only the counters move.
+__device__ __forceinline__ void wave_exit(igdsp_aggregate *agg, uint32_t rank, AggBlock &b, uint32_t nwaves, uint32_t lane,
+                                          uint32_t *gq, uint32_t G, uint64_t sumsq, uint64_t samples, uint32_t bm_sum, uint32_t peak,
+                                          uint32_t frames, uint32_t n_silent, uint32_t n_clipped)
+{
+    // (all 64 lanes adding into one LDS address measured 6 us per block: same-address LDS atomics run one lane at a time)
+    uint64_t tot = 0, smp = 0;
+    uint32_t bm = 0, pk = 0;
+    if (agg != nullptr) {
+        tot = wave_sum_u64(sumsq);
+        smp = wave_sum_u64(samples);
+        bm = wave_reduce_dpp(bm_sum, OpAdd{});
+        pk = wave_reduce_dpp(peak, OpMax{});
+    }
+    if (lane == 0) {
+        if (agg != nullptr) {
+            atomicAdd(&b.sumsq, (unsigned long long)tot);
+            atomicAdd(&b.samples, (unsigned long long)smp);
+            atomicAdd(&b.bm_sum, bm);
+            atomicMax(&b.peak, pk);
+            atomicAdd(&b.frames, frames);
+            atomicAdd(&b.n_silent, n_silent);
+            atomicAdd(&b.n_clipped, n_clipped);
+        }
+        // LDS operations of one wave execute in order, so every add above has landed when the counter moves
+        if (__hip_atomic_fetch_add(&b.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == nwaves - 1u) {
+            if (agg != nullptr && b.frames != 0u) {
+                atomicAdd((unsigned long long *)&agg->sumsq, b.sumsq);
+                atomicAdd((unsigned long long *)&agg->samples, b.samples);
+                atomicAdd((unsigned long long *)&agg->frames, (unsigned long long)b.frames);
+                atomicAdd((unsigned long long *)&agg->n_silent, (unsigned long long)b.n_silent);
+                atomicAdd((unsigned long long *)&agg->n_clipped, (unsigned long long)b.n_clipped);
+                atomicAdd((unsigned long long *)&agg->byte_mean_sum, (unsigned long long)b.bm_sum);
+                atomicMax((unsigned long long *)&agg->peak_slot[rank & (IGDSP_AGG_MAX_RANKS - 1)], (unsigned long long)b.peak);
+            }
+            if (gq != nullptr && atomicAdd(gq + 1, 1u) == G - 1u) { gq[0] = 0u; gq[1] = 0u; }
+        }
+    }
+}
+
 // ============================================================================
 // Shared machinery of the tuned n == 160 kernels (k_meter_chunk64, k_meter_rtp64, k_roundtrip_chunk64).
 //

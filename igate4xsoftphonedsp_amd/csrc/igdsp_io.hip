@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -464,7 +465,8 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
             // inputs: the chunks of source A themselves plus chunks that write slowly against it (the same class)
             if (in_chunks > kSrcChunks) walk(0, in_chunks - kSrcChunks, slow_A, poolA);
             const bool want_spread = bulk_chunks >= 8;
-            walk(0, rec_chunks + bulk_chunks + (want_spread ? kSrcChunks : 0), fast_A, poolB);
+            // (with a bulk output the pool also has to yield source B and enough members of either class to re-seed it from)
+            walk(0, want_spread ? std::max<size_t>(rec_chunks + bulk_chunks + kSrcChunks, 4 * kSrcChunks) : rec_chunks + bulk_chunks, fast_A, poolB);
 
             // 2nd split, for bulk outputs: which destinations are fast against the inputs' class AND against the first other
             // class?  Source B = the first ten pool chunks (consecutive chunks of one run): a chunk that writes slowly against it
@@ -472,56 +474,116 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
             // allocation sequence, so the walk continues from where the pool ended until the second halves of the bulk buffers
             // are covered, or the exploration limit is reached (then B serves both halves).
             if (ok && want_spread && poolB.size() >= kSrcChunks + rec_chunks + bulk_chunks - bulk_chunks / 2) {
-                const size_t need_c = bulk_chunks / 2;
+                const size_t need_c = bulk_chunks / 2, need_b = rec_chunks + bulk_chunks - need_c;
                 float tbmin = 1e30f, tbmax = 0.f;
-                auto is_C = [&](size_t idx) {
+                auto timeB = [&](size_t idx) {           // chunk idx against source B (once); false: not a candidate, or a failure
                     Chunk &c = X.chunks[idx];
-                    if (c.in_src || !fast_A(idx) || !ok) return false;
+                    if (c.in_src || !ok) return false;
                     if (c.tB < 0.f) {
                         float t = 0.f;
                         if (!X.probe(idx, X.sources[srcB], &t, "B")) { ok = false; return false; }
                         c.tB = t;
                         tbmin = std::min(tbmin, t); tbmax = std::max(tbmax, t);
                     }
-                    return c.tB < thr_fast;          // the B test streams the same bytes as the A test: same two levels
+                    return true;
                 };
-                auto split = [&](const std::vector<size_t> &sb) {
-                    ok = X.make_source(sb, &srcB);
-                    poolC.clear();
-                    tbmin = 1e30f; tbmax = 0.f;
-                    for (size_t k : poolB) if (ok && !X.chunks[k].in_src && is_C(k) && poolC.size() < need_c) poolC.push_back(k);   // every pool chunk gets timed
-                    if (ok && poolC.size() < need_c) {
-                        taken.assign(taken.size(), 0);
-                        for (size_t k : poolC) { if (taken.size() <= k) taken.resize(k + 1, 0); taken[k] = 1; }
-                        walk(poolB.back() + 1, need_c, is_C, poolC);
+                // Levels of the pool against the current source B, by two-means over the measured times (robust against a stray
+                // sample, which max / min are not): cC / cB = centre of the fast / slow group.  A destination is slow against a source
+                // in proportion to the share of the source that is of its own class, so with a source that mixes the two classes the
+                // two groups are still the two classes, only closer together.
+                float cB = 0.f, cC = 0.f, thrB = 0.f, thrC = 0.f;
+                size_t nB = 0, nC = 0;
+                auto levels = [&]() {
+                    float lo = tbmin, hi = tbmax;
+                    for (int it = 0; it < 12; ++it) {
+                        double sl = 0, sh = 0; size_t nl = 0, nh = 0;
+                        for (size_t k : poolB) {
+                            const float t = X.chunks[k].tB;
+                            if (t < 0.f) continue;
+                            if (std::fabs(t - lo) <= std::fabs(t - hi)) { sl += t; ++nl; } else { sh += t; ++nh; }
+                        }
+                        if (nl) lo = (float)(sl / (double)nl);
+                        if (nh) hi = (float)(sh / (double)nh);
+                        nC = nl; nB = nh;
                     }
-                    if (X.debug) std::fprintf(stderr, "[igdsp_io] third class: %zu of %zu chunks (levels vs B %.4f / %.4f)\n", poolC.size(), need_c, tbmax, tbmin);
-                    X.drop_source(srcB);
+                    cC = lo; cB = hi;
                 };
-                split(std::vector<size_t>(poolB.begin(), poolB.begin() + kSrcChunks));
-                if (ok && poolC.size() < need_c && tbmax > 1.03f * tbmin && tbmax < kPure * tbmin) {
-                    // compressed levels: the ten consecutive chunks of source B mix the two other classes (they can interleave chunk by
-                    // chunk).  Each of the two groups the mixed source separates IS one class: re-seed B from the slower group.
-                    std::vector<size_t> grp;
-                    const float mid = 0.5f * (tbmin + tbmax);
-                    for (size_t k = 0; k < X.chunks.size() && grp.size() < kSrcChunks; ++k)
-                        if (X.chunks[k].tB > mid && X.chunks[k].tA >= 0.f && X.chunks[k].tA < thr_fast) grp.push_back(k);
-                    if (grp.size() == kSrcChunks) {
-                        if (X.debug) std::fprintf(stderr, "[igdsp_io] source B is mixed, re-seeding from the slow group\n");
-                        for (auto &c : X.chunks) c.tB = -1.f;
-                        split(grp);
+                auto set_thresholds = [&]() { const float mid = 0.5f * (cB + cC), m = 0.2f * (cB - cC); thrB = mid + m; thrC = mid - m; };
+                auto is_C = [&](size_t idx) { return fast_A(idx) && timeB(idx) && X.chunks[idx].tB < thrC; };
+                auto is_B = [&](size_t idx) { return fast_A(idx) && timeB(idx) && X.chunks[idx].tB > thrB; };
+                // Every pool chunk against a candidate source.  0: two well separated levels, or one level at the slow mark (the
+                // source is one class and so is the pool).  1: two levels closer than pure classes give (a mixed source: they can
+                // interleave chunk by chunk).  2: one level in the middle (the source holds the two classes evenly: separates nothing).
+                auto try_source = [&](const std::vector<size_t> &sb) {
+                    for (auto &c : X.chunks) c.tB = -1.f;
+                    tbmin = 1e30f; tbmax = 0.f;
+                    ok = X.make_source(sb, &srcB);
+                    for (size_t k : poolB) if (ok) (void)timeB(k);
+                    int v = -1;
+                    if (ok) {
+                        levels();
+                        const float sep = cB / cC;
+                        if (sep < 1.025f) {
+                            const float level = (cB * (float)nB + cC * (float)nC) / (float)std::max<size_t>(1, nB + nC);
+                            v = level >= tmax / 1.025f ? 0 : 2;
+                            cB = level; cC = level * tmin / tmax;          // all of the pool is class B: the other level is the A test's
+                        } else v = sep >= 1.10f ? 0 : 1;
+                        set_thresholds();
+                    }
+                    if (X.debug) std::fprintf(stderr, "[igdsp_io] source B from chunk %zu: levels %.4f (%zu) / %.4f (%zu) -> %s\n", sb[0], cB, nB, cC, nC,
+                                              v == 0 ? "one class" : (v == 1 ? "mixed" : (v == 2 ? "evenly mixed" : "failed")));
+                    return v;
+                };
+                int verdict = -1;
+                bool have_src = false;
+                for (size_t st = 1; st <= 3 && ok && verdict != 0; ++st) {    // ten consecutive pool chunks, then every 2nd, every 3rd
+                    std::vector<size_t> sb;
+                    for (size_t k = 0; k < poolB.size() && sb.size() < kSrcChunks; k += st) sb.push_back(poolB[k]);
+                    if (sb.size() < kSrcChunks) break;
+                    for (int tries = 0; ok; ++tries) {
+                        verdict = try_source(sb);
+                        have_src = true;
+                        if (verdict != 1 || tries == 2) break;
+                        // a mixed source: each group it separates is one class — re-seed from ten members of the larger group
+                        std::vector<size_t> gb, gc;
+                        for (size_t k : poolB) {
+                            const Chunk &c = X.chunks[k];
+                            if (c.in_src || c.tB < 0.f) continue;
+                            if (c.tB > thrB) gb.push_back(k); else if (c.tB < thrC) gc.push_back(k);
+                        }
+                        std::vector<size_t> &grp = gb.size() >= gc.size() ? gb : gc;
+                        if (grp.size() < kSrcChunks) break;
+                        grp.resize(kSrcChunks);
+                        X.drop_source(srcB);
+                        sb = grp;
                         ++R.reseeds;
                     }
+                    if (verdict == 1 && cB / cC >= 1.045f) verdict = 0;      // closer than pure classes, yet clearly two groups: good enough to sort by
+                    if (verdict != 0 && have_src) { X.drop_source(srcB); have_src = false; }
                 }
-                if (ok && poolC.size() >= std::max<size_t>(4, need_c / 2)) {
-                    R.classes_found = 3;
-                    std::vector<char> is_c(X.chunks.size(), 0);
-                    for (size_t k : poolC) is_c[k] = 1;
-                    // pool B keeps only chunks that are NOT in the third class: timed slow against B, or never timed against it
-                    std::vector<size_t> b;
-                    for (size_t k : poolB) if (!is_c[k] && !(X.chunks[k].tB >= 0.f && X.chunks[k].tB < thr_fast)) b.push_back(k);
-                    poolB = b;
-                } else poolC.clear();
+                if (ok && verdict == 0) {
+                    // the pool, classified: source chunks and slow destinations are class B, fast destinations class C, anything between
+                    // the levels (a chunk that itself mixes classes) is left out; what is still missing is searched further along
+                    std::vector<size_t> cb, cc;
+                    for (size_t k : poolB) {
+                        const Chunk &c = X.chunks[k];
+                        if (c.in_src || c.tB > thrB) cb.push_back(k);
+                        else if (c.tB >= 0.f && c.tB < thrC) cc.push_back(k);
+                    }
+                    taken.assign(taken.size(), 0);
+                    for (size_t k : poolB) { if (taken.size() <= k) taken.resize(k + 1, 0); taken[k] = 1; }
+                    const size_t from = poolB.back() + 1;
+                    if (cc.size() < need_c) walk(from, need_c, is_C, cc);
+                    const size_t want_b = need_b + (cc.size() < need_c ? need_c - cc.size() : 0);   // B also serves what C could not
+                    if (ok && cb.size() < want_b) walk(from, want_b, is_B, cb);
+                    if (X.debug) std::fprintf(stderr, "[igdsp_io] split: class B %zu of %zu chunks, class C %zu of %zu\n", cb.size(), need_b, cc.size(), need_c);
+                    if (ok && cc.size() >= std::max<size_t>(4, need_c / 2)) {
+                        R.classes_found = 3;
+                        poolB = cb;
+                        poolC = cc;
+                    }
+                }
+                if (have_src) X.drop_source(srcB);
             }
             // the inputs get source A's own chunks first
             if (ok) {
@@ -590,12 +652,60 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
             }
         }
     }
+    // Releasing the exploration chunks leaves the memory system busy for a while: the driver clears freed device memory in the
+    // background at ~30-40 GB/s (measured: 104 GB released -> the same buffers stream ~5 % slower and k_meter_chunk64 runs
+    // 1.5 % slower for 2-3 s; 56 GB -> 1.5-2 s; 17 GB -> ~0.5 s; then both return to the level of the search).  The call only
+    // returns when that is over: at least released bytes / 25 GB/s, and until the finished set streams at the speed it had
+    // BEFORE the release (t_ref, taken here; the wait follows the last mapping).  IGDSP_IO_SETTLE=0 skips the wait.
+    size_t released_chunks = 0;
+    for (const auto &c : X.chunks) if (!c.used) ++released_chunks;
+    float t_ref = 0.f;
+    const void *settle_rd = nullptr;
+    void *settle_wr = nullptr;
+    size_t settle_n = 0;
+    if (ok && want_place && R.placed) {
+        int in0 = -1, out0 = -1;
+        for (uint32_t i = 0; i < n_bufs; ++i) {
+            if (bufs[i].role == IGDSP_IO_INPUT) { if (in0 < 0 || nch[i] > nch[in0]) in0 = (int)i; }
+            else if (out0 < 0) out0 = (int)i;
+        }
+        if (in0 >= 0 && out0 >= 0) {
+            settle_n = std::min(X.probe_n, std::min(nch[in0] * chunk, 10 * (nch[out0] * chunk - 4096)) / 10240 * 10240);
+            settle_rd = set->maps[in0].va; settle_wr = set->maps[out0].va;
+            const size_t keep = X.probe_n;
+            X.probe_n = settle_n;
+            float t = 0.f;
+            if (settle_n >= ((size_t)256 << 20) && X.time_pair(settle_rd, settle_wr, &t) && X.time_pair(settle_rd, settle_wr, &t)) t_ref = t;
+            X.probe_n = keep;
+        }
+    }
     X.cleanup();                                    // exploration leftovers go back before anything else is allocated
     for (uint32_t role = 0; role < 3 && ok; ++role)
         for (uint32_t i = 0; i < n_bufs && ok; ++i)
             if (bufs[i].role == role && set->maps[i].handles.size() < nch[i]) ok = map_fresh(i);
     if (!ok) { (void)hipGetLastError(); return finish(fail(ctx, IGDSP_ENOMEM, "igdsp_io_alloc: mapping chunks")); }
     for (uint32_t i = 0; i < n_bufs; ++i) bufs[i].ptr = set->maps[i].va;
+    if (const char *e = std::getenv("IGDSP_IO_SETTLE")) if (std::atoi(e) == 0) t_ref = 0.f;
+    if (t_ref > 0.f) {
+        Explorer Y;
+        Y.ctx = ctx; Y.s = ctx->stream; Y.probe_n = settle_n;
+        const auto w0 = std::chrono::steady_clock::now();
+        if (hipEventCreate(&Y.ea) == hipSuccess && hipEventCreate(&Y.eb) == hipSuccess) {
+            const float min_wait = std::min(6000.f, (float)((double)released_chunks * (double)chunk / 25e9 * 1e3));
+            int quiet = 0;
+            for (;;) {
+                float t = 0.f;
+                if (!Y.time_pair(settle_rd, settle_wr, &t)) break;
+                quiet = t <= 1.012f * t_ref ? quiet + 1 : 0;
+                const float waited = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
+                if (std::getenv("IGDSP_IO_DEBUG")) std::fprintf(stderr, "[igdsp_io] settle: %.4f ms against %.4f before the release (%.0f of >= %.0f ms)\n", t, t_ref, waited, min_wait);
+                if ((quiet >= 2 && waited >= min_wait) || waited > 8000.f) break;
+                std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            }
+        }
+        R.settle_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        Y.cleanup();
+    }
     if (std::getenv("IGDSP_IO_DEBUG") && want_place && R.placed) {   // the same check once more with every exploration chunk released
         Explorer Y;
         Y.ctx = ctx; Y.s = ctx->stream; Y.probe_n = kSrcChunks * (chunk - 4096) / 10240 * 10240;

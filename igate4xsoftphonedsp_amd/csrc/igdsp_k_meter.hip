@@ -239,7 +239,7 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
     uint64_t *__restrict__ diag = nullptr, uint32_t *__restrict__ gqueue = nullptr)
 {
     constexpr int kWaves = ChunkGeom<STORE_PCM>::kWaves;
-    __shared__ uint2 lds[kLutEntries + kWaves * kStripEntries + (STORE_PCM ? kWaves * 256 : 0)];   // 64 KiB LUT + 5 KiB strip per wave (+ 2 KiB PCM transposition scratch)
+    __shared__ uint2 lds[kLutEntries + kWaves * kStripEntries + (STORE_PCM ? kWaves * 256 : 0)];        // LUT + 5 KiB strip per wave (+ 2 KiB PCM transposition scratch)
     // Work queue.  A *batch* = kWaves consecutive super-chunks.  The block's first batch is static (its
     // blockIdx); further batches come from ONE device-wide counter (gqueue[0], one atomic per batch, i.e.
     // per ~160 KiB of input), so fast CUs take more and the launch has no inter-CU tail.  Inside the block
@@ -247,6 +247,7 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
     // prefetches the id of batch j+1, so nobody waits for the device atomic's latency.
     constexpr int kRing = 8;
     __shared__ uint32_t q_next, q_batch[kRing], q_tag[kRing];
+    __shared__ AggBlock aggb;
     uint64_t d_t0 = 0, d_t1 = 0, d_iter = 0, d_rt0 = 0, d_setup = 0, d_px = 0, d_py = 0, d_red = 0;
     if (DIAG) { d_t0 = now_cycles(); d_rt0 = __builtin_amdgcn_s_memrealtime(); }
     const uint32_t G = gridDim.x;
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
     fill_lut(lds);
     if (threadIdx.x == 0) {
         q_next = kWaves;                                         // slots 0..kWaves-1 = the waves' first picks
+        agg_block_init(aggb);
         for (int i = 0; i < kRing; ++i) q_tag[i] = 0xFFFFFFFFu;
         q_batch[0] = blockIdx.x; q_tag[0] = 0u;
         q_batch[1] = gqueue ? gb1 + G : blockIdx.x + G; q_tag[1] = 1u;
@@ -372,21 +374,16 @@ __global__ __launch_bounds__(ChunkGeom<STORE_PCM>::kWaves * 64) void k_meter_chu
             cur_pt = nxt_pt;
         }
     }
-    if (gqueue != nullptr) {                   // the last block out re-arms the device counter for the next launch
-        __syncthreads();
-        if (threadIdx.x == 0 && atomicAdd(gqueue + 1, 1u) == G - 1u) { gqueue[0] = 0u; gqueue[1] = 0u; }
-    }
     if (DIAG && lane == 0 && diag != nullptr) {
         uint64_t *o = diag + (uint64_t)(blockIdx.x * kWaves + wave) * 12u;
         o[0] = d_t0; o[1] = d_t1; o[2] = now_cycles(); o[3] = d_setup; o[4] = d_px; o[5] = d_iter; o[6] = d_py;
         o[7] = __builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID, bits [3:0]
         o[8] = d_rt0; o[9] = __builtin_amdgcn_s_memrealtime(); o[10] = d_red; o[11] = wave;
     }
-    if (AGG && agg != nullptr) {  // kernel-argument uniform: every thread of the block takes the same side
-        const bool l0 = lane == 0u;  // the wave-uniform counts enter the wave reduction once, through lane 0
-        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kWaves, a_sumsq, l0 ? (uint64_t)u_frames * kFrame : 0ull, l0 ? u_frames : 0u,
-                         l0 ? u_sil : 0u, l0 ? u_clip : 0u, a_bm, a_peak);
-    }
+    // End of the wave's work, no barrier: its aggregate partials go into the block accumulator; the block's last wave out
+    // commits the block totals and counts the block as finished (the last BLOCK out re-arms the device queue for the next launch).
+    wave_exit(AGG ? agg : nullptr, rank, aggb, (uint32_t)kWaves, lane, gqueue, G, a_sumsq, lane == 0u ? (uint64_t)u_frames * kFrame : 0ull,
+              a_bm, a_peak, u_frames, u_sil, u_clip);
 }
 
 // ============================================================================
@@ -705,10 +702,11 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
     constexpr int kStrip = kSuperFrames * QP;
     __shared__ uint2 lds[kLutEntries + kWaves * kStrip + (STORE ? kWaves * 256 : 0)];   // LUT, strips (+ 2 KiB PCM transposition scratch per wave)
     __shared__ BlockQueue<kWaves> bq;
+    __shared__ AggBlock aggb;
     uint32_t gb1 = 0;
     if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);
     fill_lut(lds);
-    if (threadIdx.x == 0) bq_init(bq, gqueue, gridDim.x, gb1);
+    if (threadIdx.x == 0) { bq_init(bq, gqueue, gridDim.x, gb1); agg_block_init(aggb); }
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -891,12 +889,8 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
             cur_pt = nxt_pt;
         }
     }
-    bq_finish(gqueue, G);
-    if (AGG && agg != nullptr) {
-        const bool l0 = lane == 0u;
-        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kWaves, a_sumsq, l0 ? (uint64_t)u_frames * n : 0ull, l0 ? u_frames : 0u,
-                         l0 ? u_sil : 0u, l0 ? u_clip : 0u, a_bm, a_peak);
-    }
+    wave_exit(AGG ? agg : nullptr, rank, aggb, (uint32_t)kWaves, lane, gqueue, G, a_sumsq, lane == 0u ? (uint64_t)u_frames * n : 0ull,
+              a_bm, a_peak, u_frames, u_sil, u_clip);
 }
 
 hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t *payload, const uint8_t *codec,

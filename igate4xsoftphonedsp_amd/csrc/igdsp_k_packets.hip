@@ -111,10 +111,11 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     if (MIXED) hdr = 12u;
     __shared__ uint2 lds[kLutEntries + kRtpWaves * kRtpStrip];
     __shared__ BlockQueue<kRtpWaves> bq;
+    __shared__ AggBlock aggb;
     uint32_t gb1 = 0;
     if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);
     fill_lut(lds);
-    if (threadIdx.x == 0) bq_init(bq, gqueue, gridDim.x, gb1);
+    if (threadIdx.x == 0) { bq_init(bq, gqueue, gridDim.x, gb1); agg_block_init(aggb); }
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -276,12 +277,7 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
             cur_radio = nxt_radio;
         }
     }
-    bq_finish(gqueue, G);
-    if (AGG && agg != nullptr) {
-        const bool l0 = lane == 0u;               // the wave-uniform counts enter the wave reduction once, through lane 0
-        agg_commit_block(agg, rank, lds + kLutEntries, (uint32_t)kRtpWaves, a_sumsq, (uint64_t)a_samp, l0 ? u_frames : 0u,
-                         l0 ? u_sil : 0u, l0 ? u_clip : 0u, a_bm, a_peak);
-    }
+    wave_exit(AGG ? agg : nullptr, rank, aggb, (uint32_t)kRtpWaves, lane, gqueue, G, a_sumsq, (uint64_t)a_samp, a_bm, a_peak, u_frames, u_sil, u_clip);
 }
 
 // ============================================================================

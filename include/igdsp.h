@@ -389,7 +389,7 @@ typedef struct igdsp_io_report {
     float    probe_ms_same;    /* bare probe stream (1.25 GiB read + 1/10 written) writing into the class it reads     */
     float    probe_ms_other;   /* ... writing into another class                                                       */
     float    setup_ms;         /* host wall time of the call                                                           */
-    float    reserved2;
+    float    settle_ms;        /* of setup_ms: waiting for the memory system to go quiet after the search released its chunks */
 } igdsp_io_report;
 typedef struct igdsp_io_set igdsp_io_set;
 int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t explore_limit_bytes,

@@ -5,7 +5,7 @@
 # Counters of one hardware block per pass only (tools/pmc_mode.sh explains why); every profiled run sits under a timeout.
 # Outputs land under gpurun_out/prof_<tag>/<mode>/<pass>/ ; tools/summarize_profile.py <tag> turns them into profiles/.
 tag=${1:-r02}; shift
-modes=${@:-"meter store roundtrip depayload rtp packets encode wav meter164"}
+modes=${@:-"meter store roundtrip depayload rtp packets encode wav meter164 store164 roundtrip164"}
 root=/root/repo/gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
 run() {  # run <mode> <pass> <rocprof args...>
@@ -13,7 +13,7 @@ run() {  # run <mode> <pass> <rocprof args...>
     local out=$root/$mode/$pass
     mkdir -p $out
     local margs="--mode $mode"
-    [ "$mode" = meter164 ] && margs="--mode meter --frame-bytes 164"
+    case $mode in *164) margs="--mode ${mode%164} --frame-bytes 164";; esac
     timeout -k 10 200 rocprofv3 "$@" --output-format csv -d $out -- python3 /root/repo/bench.py $margs --steps 20 --warmup 3 --no-cpu-baseline --no-stream-calib --placement abi > $out.log 2>&1
     local rc=$?
     echo "$mode/$pass rc=$rc"
@@ -34,5 +34,7 @@ python3 /root/repo/bench.py > $root/bench_meter_unprofiled.json 2> $root/bench_m
 for m in store roundtrip depayload rtp packets encode wav; do
     python3 /root/repo/bench.py --mode $m --no-cpu-baseline > $root/bench_${m}_unprofiled.json 2> $root/bench_${m}_unprofiled.err
 done
-python3 /root/repo/bench.py --frame-bytes 164 --no-cpu-baseline > $root/bench_meter164_unprofiled.json 2> $root/bench_meter164_unprofiled.err
+for m in meter store roundtrip; do
+    python3 /root/repo/bench.py --mode $m --frame-bytes 164 --no-cpu-baseline > $root/bench_${m}164_unprofiled.json 2> $root/bench_${m}164_unprofiled.err
+done
 ls $root
