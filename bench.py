@@ -333,8 +333,6 @@ def main():
         OUT = P
     else:
         OUT = BufSet("abi")
-        if os.environ.get("IGDSP_BENCH_SETTLE_S"):      # experiment: idle time between the buffer set-up and the first launch
-            torch.cuda.synchronize(); time.sleep(float(os.environ["IGDSP_BENCH_SETTLE_S"]))
 
     def step(i: int, coll: bool = True):
         agg = agg_ring[i] if coll else scratch_agg   # the comparison pass of --force-collective must not add into the ring again
