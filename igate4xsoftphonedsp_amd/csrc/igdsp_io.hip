@@ -327,7 +327,10 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
 
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    size_t limit = explore_limit_bytes ? explore_limit_bytes : (size_t)(0.6 * (double)free_b);
+    // default: 60 % of what is free; 85 % when bulk outputs want a THIRD class (the allocator tends to hand that one out last)
+    double dflt = bulk_chunks >= 8 ? 0.85 : 0.6;
+    if (const char *e = std::getenv("IGDSP_IO_LIMIT_FRAC")) dflt = std::atof(e);
+    size_t limit = explore_limit_bytes ? explore_limit_bytes : (size_t)(dflt * (double)free_b);
     limit = std::min(limit, (size_t)(0.9 * (double)free_b));
 
     // fresh consecutive chunks for what buffer i still lacks (no class wanted / known)

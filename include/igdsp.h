@@ -365,7 +365,7 @@ int igdsp_dev_alloc_far(igdsp_ctx *ctx, void **d_ptr, size_t bytes, const void *
  *                    in the other (the kernels visit the two halves of a bulk output alternately).
  * Start-up use: synchronous, takes 0.2-10 s (the search, then report->settle_ms of waiting until the driver has finished
  * clearing the memory the search gave back: launches run 1-5 % slow while it does); temporarily holds up to
- * explore_limit_bytes (0 = 60 % of the free device memory) of chunks while it searches and releases everything it does not
+ * explore_limit_bytes (0 = 60 % of the free device memory, 85 % when BULK buffers want a third class) of chunks while it searches and releases everything it does not
  * hand out.  The pointers stay valid until igdsp_io_free.  If the virtual-memory API is missing, the largest input is < 512 MiB (the probe then measures the
  * Infinity Cache, and placement does not matter) or no second class is found, the buffers are still allocated and
  * report->placed is 0.  Buffer sizes are rounded up to whole chunks internally. */

@@ -872,6 +872,8 @@ def test_io_alloc_places_buffers_and_they_work(ctx, orc):
             assert (int(st[fi]["sumsq"]), int(st[fi]["peak"]), int(st[fi]["byte_mean"])) == (int(e["sumsq"]), int(e["peak"]), int(e["byte_mean"]))
         if rep["classes_found"] >= 2:
             assert rep["placed"] == 1 and rep["probe_ms_other"] <= 0.92 * rep["probe_ms_same"]
+            # the call waits until the driver has cleared what the search gave back: bounded, and part of setup_ms
+            assert 0.0 < rep["settle_ms"] <= 9000.0 and rep["settle_ms"] <= rep["setup_ms"]
             # The library's two levels come from its own probe stream on freshly created (zero) memory; with real data the same
             # stream runs ~4 % slower at either level, so the placed pair is compared, on the same data, with (i) a pair the
             # library builds in ONE class on purpose (both buffers given the INPUT role: what consecutive plain allocations
