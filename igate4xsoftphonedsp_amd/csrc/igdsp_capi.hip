@@ -583,6 +583,16 @@ int igdsp_internal_stream_rw(igdsp_ctx *ctx, const void *d_src, size_t bytes, vo
     return IGDSP_OK;
 }
 
+// Calibration-only (not in include/igdsp.h): the dword-aligned piece pattern of the packed packet / strided kernels, no per-sample work
+// (launch_stream_pieces).  src needs n_items * 64 * stride + 16 bytes, dst n_items KiB, dst2 (optional) n_items * 512 bytes.
+int igdsp_internal_stream_pieces(igdsp_ctx *ctx, const void *d_src, uint32_t n_items, uint32_t stride, uint32_t hdr, int mode, int rows, void *d_dst, void *d_dst2, void *stream)
+{
+    if (!ctx || !d_src || !d_dst || (stride & 3u) || stride < 16u * (uint32_t)(rows - (mode == 0 ? 2 : 1))) return IGDSP_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_stream_pieces(cfg_of(ctx), d_src, n_items, stride, hdr, mode, rows, d_dst, d_dst2, pick(ctx, stream)));
+    return IGDSP_OK;
+}
+
 // Calibration-only (not in include/igdsp.h): bare read : write mix, r and w 1 KiB pieces per wave item
 // (pairs built: 0:8, 8:8, 8:4, 4:8, 10:1, 10:0, 8:1, 8:2, 20:2, 5:1; `waves` per block 1..16); src needs n_items * r KiB, dst n_items * w KiB.
 int igdsp_internal_stream_mix(igdsp_ctx *ctx, const void *d_src, void *d_dst, uint32_t n_items, int r, int w, int waves, void *stream)

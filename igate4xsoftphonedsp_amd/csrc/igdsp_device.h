@@ -294,6 +294,40 @@ __device__ __forceinline__ uint2 lut_at(const uint2 *lut, uint32_t t, uint32_t o
     return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(lut) + addr);
 }
 
+// The record-only kernels that are NOT bound by HBM (k_meter_strided: 6 % under the bare stream with its own access pattern,
+// tools/stream_pieces.py) read a 4-byte LUT: entry = m * m alone (m = |x| >> 2, 26 bits).  A wave-wide ds_read_b32 moves 256 B
+// through the 128 B/clk LDS port in 2 clocks where the ds_read_b64 of the 8-byte table takes 4, the lookup result needs one
+// register instead of two, and NO per-sample masking is left: the row is the raw code byte (256 rows x 256 B, the v_perm address
+// trick again; the sign bit just selects a duplicate), inside a row 32 replicas of the mu-law entry then 32 of the A-law entry,
+// so the law is one bit of the per-piece offset instead of bit 7 of every code byte.  64 KiB for both laws.  The peak comes from
+// the SAME value: max(m * m) is the square of max(m), and one float square root per 16-sample piece turns it back (isqrt_m2:
+// exact, see there).  (k_meter_chunk64 IS bound by HBM: it measured 0.2278 ms with either table and keeps the 8-byte one, which
+// the PCM variants need anyway.)
+constexpr int kLut32Words = 256 * 64;
+__device__ __forceinline__ void fill_lut32(uint32_t *lut)
+{
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kLut32Words; i += blockDim.x) {
+        const uint32_t e = ((i & 32u) << 2) | ((i >> 6) & 0x7Fu);   // law << 7 | code7
+        const uint32_t m = ((e & 0x80u) ? alaw_abs(e) : ulaw_abs(e)) >> 2;
+        lut[i] = m * m;
+    }
+}
+
+__device__ __forceinline__ uint32_t lut32_at(const uint32_t *lut, uint32_t w, uint32_t off, uint32_t sel)
+{
+    // byte address = off | (byte_k(w) << 8), off = replica * 4 | law << 7; w holds raw code bytes
+    const uint32_t addr = __builtin_amdgcn_perm(w, off, sel);
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lut) + addr);
+}
+
+// m from m * m (m <= 8064): (float)v is off by <= 2^-24 relative, v_sqrt_f32 by 1 ulp, so the root is within 0.002 of the
+// integer m and rounding to nearest returns it exactly (every G.711 magnitude of both laws is checked through the record's peak
+// in tests/test_gpu_parity.py).
+__device__ __forceinline__ uint32_t isqrt_m2(uint32_t v)
+{
+    return (uint32_t)(__builtin_amdgcn_sqrtf((float)v) + 0.5f);
+}
+
 typedef short v2i16 __attribute__((ext_vector_type(2)));
 typedef unsigned short v2u16_t __attribute__((ext_vector_type(2)));
 

@@ -699,40 +699,51 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
     static_assert(Q == 1 || Q >= 4, "the probe bytes 28 / 38 / 48 are taken from pieces 1 / 2 / 3");
     constexpr int QP = Q + (TAIL ? 1 : 0);                       // pieces per frame
     constexpr int kWaves = StridedGeom<QP, STORE>::kWaves;
-    constexpr int kStrip = kSuperFrames * QP;
-    __shared__ uint2 lds[kLutEntries + kWaves * kStrip + (STORE ? kWaves * 256 : 0)];   // LUT, strips (+ 2 KiB PCM transposition scratch per wave)
+    constexpr int kRow = QP | 1;                                 // strip row of a frame: an ODD number of 8-byte entries, so the fold's ds_read_b64 meet no bank twice
+    constexpr int kStrip = kSuperFrames * kRow;                  // (rows of 8 entries = 16 banks put lanes l, l + 2, ... on the same banks: 8-way conflicts at n = 128)
+    constexpr int kLutU2 = STORE ? kLutEntries : kLut32Words / 2;   // records only: the 4-byte m * m table (32 KiB, igdsp_device.h); with PCM the 8-byte one
+    __shared__ uint2 lds[kLutU2 + kWaves * kStrip + (STORE ? kWaves * 256 : 0)];        // LUT, strips (+ 2 KiB PCM transposition scratch per wave)
     __shared__ BlockQueue<kWaves> bq;
     __shared__ AggBlock aggb;
     uint32_t gb1 = 0;
     if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);
-    fill_lut(lds);
+    if (STORE) fill_lut(lds); else fill_lut32(reinterpret_cast<uint32_t *>(lds));
     if (threadIdx.x == 0) { bq_init(bq, gqueue, gridDim.x, gb1); agg_block_init(aggb); }
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint2 *strip = lds + kLutEntries + wave * kStrip;
-    uint8_t *xpose = STORE ? reinterpret_cast<uint8_t *>(lds + kLutEntries + kWaves * kStrip + wave * 256) : nullptr;
-    const uint32_t off = (lane & 31u) * 8u;
+    uint2 *strip = lds + kLutU2 + wave * kStrip;
+    uint8_t *xpose = STORE ? reinterpret_cast<uint8_t *>(lds + kLutU2 + kWaves * kStrip + wave * 256) : nullptr;
+    const uint32_t off = (lane & 31u) * (STORE ? 8u : 4u);
+    const uint32_t *l32 = reinterpret_cast<const uint32_t *>(lds);
     const uint32_t T = (n - 16u * Q) >> 2;                       // tail dwords per frame (TAIL: 1 or 2), wave-uniform
     // per-lane piece constants, two pieces per register: frame of the item (6 bits) | probe shift << 8 (24 = none) | tail
     // piece << 13, in each 16-bit half.  The byte offset of piece j inside the item follows from the frame and the piece
     // number: f * n + (tail ? n - 16 : 16 q).
     constexpr int kPk = (QP + 1) / 2;
+    constexpr bool kPoRegs = !STORE;                             // records only: the piece offsets stay in registers (the 4-byte LUT leaves room)
     uint32_t pk[kPk];
+    uint32_t po[kPoRegs ? QP : 1];
 #pragma unroll
     for (int j = 0; j < kPk; ++j) pk[j] = 0;
 #pragma unroll
     for (int j = 0; j < QP; ++j) {
         const uint32_t p = (uint32_t)j * 64u + lane, f = p / (uint32_t)QP, q = p - f * (uint32_t)QP;
         const uint32_t sh = q == 1u ? 0u : (q == 3u ? 8u : (q == 2u ? 16u : 24u));
-        pk[j >> 1] |= (f | (((TAIL && q == (uint32_t)Q) ? 24u : sh) << 8) | ((TAIL && q == (uint32_t)Q) ? 0x2000u : 0u)) << (16 * (j & 1));
+        const bool tp = TAIL && q == (uint32_t)Q;
+        pk[j >> 1] |= ((f << 2) | ((tp ? 24u : sh) << 8) | (tp ? 0x2000u : 0u)) << (16 * (j & 1));     // f * 4: also the ds_bpermute address of the frame's lane
+        if (kPoRegs) po[j] = f * n + (tp ? n - 16u : 16u * q);
     }
-    auto fr_of = [&](int j) { return __builtin_amdgcn_ubfe(pk[j >> 1], 16 * (j & 1), 6); };
+    auto fr4_of = [&](int j) { return __builtin_amdgcn_ubfe(pk[j >> 1], 16 * (j & 1), 8); };
+    auto fr_of = [&](int j) { return __builtin_amdgcn_ubfe(pk[j >> 1], 16 * (j & 1) + 2, 6); };
     auto ps_of = [&](int j) { return __builtin_amdgcn_ubfe(pk[j >> 1], 16 * (j & 1) + 8, 5); };
     auto tail_of = [&](int j) { return TAIL && ((pk[j >> 1] >> (16 * (j & 1) + 13)) & 1u) != 0u; };
     auto po_of = [&](int j) {                                    // byte offset of this lane's piece j inside an item
-        const uint32_t f = fr_of(j), q = (uint32_t)j * 64u + lane - f * (uint32_t)QP;
-        return f * n + (tail_of(j) ? n - 16u : 16u * q);
+        if constexpr (kPoRegs) return po[j];
+        else {
+            const uint32_t f = fr_of(j), q = (uint32_t)j * 64u + lane - f * (uint32_t)QP;
+            return f * n + (tail_of(j) ? n - 16u : 16u * q);
+        }
     };
     const uint32_t G = gridDim.x;
     const uint32_t n_super = n_frames / kSuperFrames;           // the launcher hands over whole items only
@@ -770,18 +781,29 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
             {
                 uint2 e[2][8];
                 uint32_t wa[2], wb[2];
+                uint32_t oj = off;
+                const uint32_t law_off = my_alaw ? 0x80u : 0u;
                 auto issue = [&](int u) {
                     const int j = u >> 1, k = u & 1;
                     wa[k] = (u & 1) ? d[j].z : d[j].x;
                     wb[k] = (u & 1) ? d[j].w : d[j].y;
-                    const uint32_t frj = fr_of(j);
-                    const uint32_t bit = frj < 32u ? (uint32_t)__builtin_amdgcn_sbfe(am_lo, frj, 1) : (uint32_t)__builtin_amdgcn_sbfe(am_hi, frj - 32u, 1);
-                    const uint32_t lmj = bit & 0x80808080u;
-                    const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lmj, tb = (wb[k] & 0x7F7F7F7Fu) | lmj;
-                    e[k][0] = lut_at(lds, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lds, ta, off, 0x0C0C0500u);
-                    e[k][2] = lut_at(lds, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lds, ta, off, 0x0C0C0700u);
-                    e[k][4] = lut_at(lds, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lds, tb, off, 0x0C0C0500u);
-                    e[k][6] = lut_at(lds, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lds, tb, off, 0x0C0C0700u);
+                    if (STORE) {
+                        const uint32_t frj = fr_of(j);
+                        const uint32_t bit = frj < 32u ? (uint32_t)__builtin_amdgcn_sbfe(am_lo, frj, 1) : (uint32_t)__builtin_amdgcn_sbfe(am_hi, frj - 32u, 1);
+                        const uint32_t lmj = bit & 0x80808080u;
+                        const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lmj, tb = (wb[k] & 0x7F7F7F7Fu) | lmj;
+                        e[k][0] = lut_at(lds, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lds, ta, off, 0x0C0C0500u);
+                        e[k][2] = lut_at(lds, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lds, ta, off, 0x0C0C0700u);
+                        e[k][4] = lut_at(lds, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lds, tb, off, 0x0C0C0500u);
+                        e[k][6] = lut_at(lds, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lds, tb, off, 0x0C0C0700u);
+                    } else {                                     // e[][].x = m * m; `peak` tracks max(m * m) until the piece is complete
+                        // the law of this piece's frame picks the row half: the frame's own lane holds it, one ds_bpermute fetches it
+                        if (k == 0) oj = off | (uint32_t)__builtin_amdgcn_ds_bpermute((int)fr4_of(j), (int)law_off);
+                        e[k][0].x = lut32_at(l32, wa[k], oj, 0x0C0C0400u); e[k][1].x = lut32_at(l32, wa[k], oj, 0x0C0C0500u);
+                        e[k][2].x = lut32_at(l32, wa[k], oj, 0x0C0C0600u); e[k][3].x = lut32_at(l32, wa[k], oj, 0x0C0C0700u);
+                        e[k][4].x = lut32_at(l32, wb[k], oj, 0x0C0C0400u); e[k][5].x = lut32_at(l32, wb[k], oj, 0x0C0C0500u);
+                        e[k][6].x = lut32_at(l32, wb[k], oj, 0x0C0C0600u); e[k][7].x = lut32_at(l32, wb[k], oj, 0x0C0C0700u);
+                    }
                 };
                 uint32_t sum = 0, peak = 0, bsum = 0;
                 uint32_t o[8];
@@ -795,16 +817,22 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
                     bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
                     sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
                     sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
-                    peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
-                    peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
+                    if (STORE) {
+                        peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
+                        peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
+                    } else {
+                        peak = max(max(peak, e[k][0].x), e[k][1].x); peak = max(max(peak, e[k][2].x), e[k][3].x);
+                        peak = max(max(peak, e[k][4].x), e[k][5].x); peak = max(max(peak, e[k][6].x), e[k][7].x);
+                    }
                     if (STORE) {
                         o[4 * k + 0] = pack_pcm(wa[k], 0, e[k][0].y, e[k][1].y); o[4 * k + 1] = pack_pcm(wa[k], 2, e[k][2].y, e[k][3].y);
                         o[4 * k + 2] = pack_pcm(wb[k], 0, e[k][4].y, e[k][5].y); o[4 * k + 3] = pack_pcm(wb[k], 2, e[k][6].y, e[k][7].y);
                     }
                     if (k == 1) {                               // piece j complete
+                        if (!STORE) peak = isqrt_m2(peak) << 2;             // max(m * m) -> |x| of the piece's loudest sample
                         uint2 ent = make_uint2(sum, peak | (bsum << 16) | probe_fail(d[j], 0xFFu << ps_of(j)));
                         if (tail_of(j)) ent = make_uint2(d[j].z, d[j].w);       // the frame's last two dwords, raw
-                        strip[j * 64 + lane] = ent;
+                        strip[j * 64 + lane + (uint32_t)(kRow - QP) * fr_of(j)] = ent;       // piece p -> row p / QP, column p % QP
                         if (STORE) {
                             // The wave's PCM for row j is ONE contiguous run: piece p = 64 j + lane puts its 32 bytes (the tail piece:
                             // the 8 T bytes of the frame's tail samples) at S(p) = 2 n f + 32 q of the item's PCM, and S grows by
@@ -845,7 +873,7 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
             const uint32_t s_after = has_next ? grab() : 0xFFFFFFFFu;
             wave_lds_fence();
             {
-                const uint2 *row = strip + lane * QP;              // the pieces of this lane's frame
+                const uint2 *row = strip + lane * kRow;            // the pieces of this lane's frame
                 uint64_t s = 0;
                 uint32_t peak = 0, bsum = 0, fail = 0, part = 0;
 #pragma unroll
@@ -861,16 +889,27 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
                     const uint2 tv = row[Q];
                     const uint32_t lm = my_alaw ? 0x80808080u : 0u;
                     const uint32_t tws[2] = {T == 2u ? tv.x : tv.y, tv.y};
+                    uint32_t tail_m2 = 0;
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
                         if ((uint32_t)t < T) {
-                            const uint32_t w = tws[t], tt = (w & 0x7F7F7F7Fu) | lm;
-                            const uint2 e0 = lut_at(lds, tt, off, 0x0C0C0400u), e1 = lut_at(lds, tt, off, 0x0C0C0500u);
-                            const uint2 e2 = lut_at(lds, tt, off, 0x0C0C0600u), e3 = lut_at(lds, tt, off, 0x0C0C0700u);
-                            s += (uint64_t)(e0.x + e1.x + e2.x + e3.x);
-                            peak = max(max(peak, e0.y), max(e1.y, max(e2.y, e3.y)));
+                            const uint32_t w = tws[t];
+                            if (STORE) {
+                                const uint32_t tt = (w & 0x7F7F7F7Fu) | lm;
+                                const uint2 e0 = lut_at(lds, tt, off, 0x0C0C0400u), e1 = lut_at(lds, tt, off, 0x0C0C0500u);
+                                const uint2 e2 = lut_at(lds, tt, off, 0x0C0C0600u), e3 = lut_at(lds, tt, off, 0x0C0C0700u);
+                                s += (uint64_t)(e0.x + e1.x + e2.x + e3.x);
+                                peak = max(max(peak, e0.y), max(e1.y, max(e2.y, e3.y)));
+                            } else {
+                                const uint32_t ot = off | (lm & 0x80u);
+                                const uint32_t q0 = lut32_at(l32, w, ot, 0x0C0C0400u), q1 = lut32_at(l32, w, ot, 0x0C0C0500u);
+                                const uint32_t q2 = lut32_at(l32, w, ot, 0x0C0C0600u), q3 = lut32_at(l32, w, ot, 0x0C0C0700u);
+                                s += (uint64_t)(q0 + q1 + q2 + q3);
+                                tail_m2 = max(tail_m2, max(max(q0, q1), max(q2, q3)));
+                            }
                             bsum = __builtin_amdgcn_sad_u8(w, 0u, bsum);
                         }
+                    if (!STORE) peak = max(peak, isqrt_m2(tail_m2) << 2);
                 }
                 const bool probe = (Q >= 4) && (fail >> 31) == 0u;  // bytes 28 / 38 / 48 exist only when n > 48
                 uint32_t bm, fl;

@@ -370,6 +370,45 @@ hipError_t launch_stream_mix(const LaunchCfg &cfg, const void *src, void *dst, u
     return hipErrorInvalidValue;
 }
 
+// Calibration of the PACKED packet kernels' access pattern, no per-sample work: item = 64 packets at `stride` bytes; every lane
+// fetches `pieces` dword-aligned 16-byte pieces per 64-lane row exactly where k_meter_rtp64<packed> / k_meter_strided fetch theirs
+// (mode 0: 12 pieces per packet = bytes 0-15, 4-19, then hdr + 16 q; mode 1: QP pieces per frame = 16 q, the last one at n - 16)
+// and stores one 1 KiB record block (+ 512 B of info in mode 0) per item.
+template <int ROWS>
+__global__ __launch_bounds__(768) void k_stream_pieces(const uint8_t *__restrict__ src, uint32_t n_items, uint32_t stride, uint32_t hdr, int mode,
+                                                        uint4 *__restrict__ dst, uint2 *__restrict__ dst2)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    uint32_t po[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const uint32_t p = (uint32_t)j * 64u + lane, f = p / (uint32_t)ROWS, q = p - f * (uint32_t)ROWS;
+        if (mode == 0) po[j] = f * stride + (q == 0u ? 0u : (q == 1u ? 4u : hdr + 16u * (q - 2u)));
+        else po[j] = f * stride + ((q == (uint32_t)ROWS - 1u && (stride & 15u)) ? stride - 16u : 16u * q);
+    }
+    for (uint32_t b = blockIdx.x; b * wpb + wave < n_items; b += gridDim.x) {
+        const uint32_t item = b * wpb + wave;
+        const uint8_t *base = src + (uint64_t)item * 64u * stride;
+        uint4 v[ROWS], acc = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) v[j] = ld16_dw(base + po[j]);
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { acc.x ^= v[j].x; acc.y ^= v[j].y; acc.z ^= v[j].z; acc.w ^= v[j].w; }
+        dst[(uint64_t)item * 64u + lane] = acc;
+        if (dst2 != nullptr) dst2[(uint64_t)item * 64u + lane] = make_uint2(acc.x, acc.y);
+    }
+}
+
+hipError_t launch_stream_pieces(const LaunchCfg &cfg, const void *src, uint32_t n_items, uint32_t stride, uint32_t hdr, int mode, int rows, void *dst, void *dst2, hipStream_t s)
+{
+    const dim3 g(cfg.compute_units), b(768);
+    const uint8_t *sp = reinterpret_cast<const uint8_t *>(src);
+#define IGDSP_PCS(R) if (rows == R) { hipLaunchKernelGGL((k_stream_pieces<R>), g, b, 0, s, sp, n_items, stride, hdr, mode, reinterpret_cast<uint4 *>(dst), reinterpret_cast<uint2 *>(dst2)); return hipGetLastError(); }
+    IGDSP_PCS(10) IGDSP_PCS(11) IGDSP_PCS(12)
+#undef IGDSP_PCS
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_stream_read(const LaunchCfg &cfg, const void *src, size_t bytes, uint64_t *sink, hipStream_t s)
 {
     if (bytes < 16) return hipSuccess;

@@ -16,8 +16,12 @@ namespace igdsp {
 // ============================================================================
 constexpr int kSlotPieces = IGDSP_SLOT_BYTES / 16;                 // 12
 constexpr int kRtpHalfLoads = kSlotPieces * kChunkFrames / 64;     // 6 loads per lane per 32-slot half
-constexpr int kRtpStrip = kSuperFrames * kSlotPieces;              // 768 entries = 6 KiB per wave
-constexpr int kRtpWaves = 12;                                      // 64 KiB LUT + 72 KiB strips
+// A frame's 12 strip entries sit in a row of 14 (112 bytes = 28 banks): the fold's six ds_read_b128 per lane then touch 8 distinct
+// bank groups per 8-lane pass.  With 12-entry rows (96 bytes = 24 banks) lanes l and l + 4 met in the same banks: the round-2
+// counters showed SQ_LDS_BANK_CONFLICT = 4.2e7 cycles per launch (a quarter of the LDS pipe's time) in the packed kernel.
+constexpr int kRtpRow = kSlotPieces + 2;
+constexpr int kRtpStrip = kSuperFrames * kRtpRow;                  // 896 entries = 7 KiB per wave
+constexpr int kRtpWaves = 12;                                      // 64 KiB LUT + 84 KiB strips
 
 // SLOT = true : 192-byte slots (size word + pad + packet at +12), every piece 16-byte aligned.
 // SLOT = false: packets packed at `stride` bytes exactly as received; piece addresses are only dword aligned.
@@ -26,7 +30,7 @@ constexpr int kRtpWaves = 12;                                      // 64 KiB LUT
 template <bool SLOT, bool MIXED = false>
 __device__ __forceinline__ void rtp_half(const uint2 *lut, uint2 *strip_half, uint4 (&d)[kRtpHalfLoads],
                                          const uint32_t am, const uint32_t (&fr)[kRtpHalfLoads], const uint32_t (&pm)[kRtpHalfLoads],
-                                         const uint32_t (&hs)[kRtpHalfLoads], const uint32_t off, const uint32_t lane,
+                                         const uint32_t off, const uint32_t lane,
                                          const uint8_t *refill_base, const uint32_t (&roff)[kRtpHalfLoads], const uint32_t nrm = 0u)
 {
     uint2 e[2][8];
@@ -60,10 +64,12 @@ __device__ __forceinline__ void rtp_half(const uint2 *lut, uint2 *strip_half, ui
             // header pieces.  SLOT: piece 0 = slot bytes 0..15 -> {size word, RTP bytes 0-3}; piece 1 = bytes 16..31.
             //                packed: piece 0 = packet bytes 0..15 -> {RTP bytes 0-3, -};      piece 1 = bytes 4..19.
             // either way piece 1 ends with {extension profile/length, ED-137 word}
-            if (hs[j] == 1u) ent = SLOT ? make_uint2(d[j].x, d[j].w) : make_uint2(0u, d[j].x);
-            if (hs[j] == 2u) ent = make_uint2(d[j].z, d[j].w);
-            strip_half[j * 64 + lane] = ent;
-            const uint32_t ro = roff[j] + ((MIXED && hs[j] == 0u) ? ((nrm >> fr[j]) & 1u) * 8u : 0u);
+            const uint32_t hsj = fr[j] >> 8;                    // 0 payload piece, 1 / 2 the two header pieces (fr = slot | hs << 8)
+            if (hsj == 1u) ent = SLOT ? make_uint2(d[j].x, d[j].w) : make_uint2(0u, d[j].x);
+            if (hsj == 2u) ent = make_uint2(d[j].z, d[j].w);
+            strip_half[j * 64 + lane + (uint32_t)(kRtpRow - kSlotPieces) * (fr[j] & 31u)] = ent;   // piece p of the half -> row p / 12, column p % 12
+            // SLOT: piece p of the half sits at p * 16 (roff[0] = this lane's piece 0; no per-piece offset registers)
+            const uint32_t ro = SLOT ? roff[0] + (uint32_t)j * 1024u : roff[j] + ((MIXED && hsj == 0u) ? ((nrm >> (fr[j] & 31u)) & 1u) * 8u : 0u);
             d[j] = SLOT ? ld_stream(reinterpret_cast<const uint4 *>(refill_base + ro)) : ld16_dw(refill_base + ro);
             sum = 0; peak = 0; bsum = 0;
         }
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
 {
     static_assert(!(SLOT && MIXED), "slots always hold 20-byte headers");
     if (MIXED) hdr = 12u;
-    __shared__ uint2 lds[kLutEntries + kRtpWaves * kRtpStrip];
+    __shared__ __attribute__((aligned(16))) uint2 lds[kLutEntries + kRtpWaves * kRtpStrip];
     __shared__ BlockQueue<kRtpWaves> bq;
     __shared__ AggBlock aggb;
     uint32_t gb1 = 0;
@@ -121,22 +127,22 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint2 *strip = lds + kLutEntries + wave * kRtpStrip;
     const uint32_t off = (lane & 31u) * 8u;
-    uint32_t pm[kRtpHalfLoads], hs[kRtpHalfLoads], fr[kRtpHalfLoads];
+    uint32_t pm[kRtpHalfLoads], fr[kRtpHalfLoads];        // fr = slot within the half | header-piece selector << 8 (shifts and v_bfe only look at the low 5 bits)
     uint32_t roff0[kRtpHalfLoads], roff1[kRtpHalfLoads];       // byte offset of this lane's pieces inside a super-chunk
 #pragma unroll
     for (int j = 0; j < kRtpHalfLoads; ++j) {
         const uint32_t p = (uint32_t)j * 64u + lane;
-        fr[j] = p / 12u;                                  // slot within the 32-slot half
-        const uint32_t q = p - fr[j] * 12u;               // piece within the slot: 0, 1 header; 2..11 payload
-        hs[j] = q < 2u ? q + 1u : 0u;
+        const uint32_t f = p / 12u;                       // slot within the 32-slot half
+        const uint32_t q = p - f * 12u;                   // piece within the slot: 0, 1 header; 2..11 payload
+        fr[j] = f | ((q < 2u ? q + 1u : 0u) << 8);
         pm[j] = q < 2u ? 0u : probe_mask(q - 2u);
         if (SLOT) {
             roff0[j] = p * 16u;
-            roff1[j] = (p + (uint32_t)(kRtpStrip / 2)) * 16u;
+            roff1[j] = (p + (uint32_t)(kChunkFrames * kSlotPieces)) * 16u;      // the second half's pieces follow the first half's 384
         } else {
             const uint32_t po = q == 0u ? 0u : (q == 1u ? 4u : hdr + 16u * (q - 2u));
-            roff0[j] = fr[j] * stride + po;
-            roff1[j] = (fr[j] + (uint32_t)kChunkFrames) * stride + po;
+            roff0[j] = f * stride + po;
+            roff1[j] = (f + (uint32_t)kChunkFrames) * stride + po;
         }
     }
     const uint32_t G = gridDim.x;
@@ -153,9 +159,9 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     auto offsets = [&](uint64_t rm, uint32_t (&o0)[kRtpHalfLoads], uint32_t (&o1)[kRtpHalfLoads]) {
 #pragma unroll
         for (int j = 0; j < kRtpHalfLoads; ++j) {
-            const uint32_t b0 = (uint32_t)(rm >> fr[j]) & 1u, b1 = (uint32_t)(rm >> (fr[j] + 32u)) & 1u;
-            o0[j] = roff0[j] + (hs[j] == 0u ? 8u * b0 : 0u);
-            o1[j] = roff1[j] + (hs[j] == 0u ? 8u * b1 : 0u);
+            const uint32_t f = fr[j] & 31u, b0 = (uint32_t)(rm >> f) & 1u, b1 = (uint32_t)(rm >> (f + 32u)) & 1u;
+            o0[j] = roff0[j] + (fr[j] < 256u ? 8u * b0 : 0u);
+            o1[j] = roff1[j] + (fr[j] < 256u ? 8u * b1 : 0u);
         }
     };
     auto ld = [&](const uint8_t *b, uint32_t o) { return SLOT ? ld_stream(reinterpret_cast<const uint4 *>(b + o)) : ld16_dw(b + o); };
@@ -201,16 +207,16 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
             if (!SLOT && sizes != nullptr) my_size = sizes[f0 + lane];
             if (MIXED) {
                 const uint64_t nrm = __ballot(nxt_radio != 0u);
-                rtp_half<SLOT, true>(lds, strip, X, am_lo, fr, pm, hs, off, lane, nbase, roff0, (uint32_t)nrm);
-                rtp_half<SLOT, true>(lds, strip + kRtpStrip / 2, Y, am_hi, fr, pm, hs, off, lane, nbase, roff1, (uint32_t)(nrm >> 32));
+                rtp_half<SLOT, true>(lds, strip, X, am_lo, fr, pm, off, lane, nbase, roff0, (uint32_t)nrm);
+                rtp_half<SLOT, true>(lds, strip + kRtpStrip / 2, Y, am_hi, fr, pm, off, lane, nbase, roff1, (uint32_t)(nrm >> 32));
             } else {
-                rtp_half<SLOT>(lds, strip, X, am_lo, fr, pm, hs, off, lane, nbase, roff0);
-                rtp_half<SLOT>(lds, strip + kRtpStrip / 2, Y, am_hi, fr, pm, hs, off, lane, nbase, roff1);
+                rtp_half<SLOT>(lds, strip, X, am_lo, fr, pm, off, lane, nbase, roff0);
+                rtp_half<SLOT>(lds, strip + kRtpStrip / 2, Y, am_hi, fr, pm, off, lane, nbase, roff1);
             }
             const uint32_t s_after = has_next ? grab() : 0xFFFFFFFFu;   // its LDS round trip hides under the fold below
             wave_lds_fence();
             {
-                const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kSlotPieces);   // 96-byte rows
+                const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kRtpRow);       // 112-byte rows, 16-byte aligned
                 const uint4 h = row[0];                   // {size word | 0, RTP bytes 0-3, ext profile/length, ED-137 word}
                 uint64_t s = 0;
                 uint32_t peak = 0, bsum = 0, fail = 0;
