@@ -178,10 +178,13 @@ __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half
 #if IGDSP_STORE_XPOSE
                 // transposition through a per-wave 2 KiB LDS scratch: lane l parks its 32 bytes at l * 32, then reads back
                 // bytes [16 l, 16 l + 16) of each KiB, so both store instructions write 1 KiB contiguous (whole lines)
-                xpose[2u * lane] = make_uint4(o[0], o[1], o[2], o[3]);
-                xpose[2u * lane + 1u] = make_uint4(o[4], o[5], o[6], o[7]);
+                // (16-byte unit u lives at u ^ ((u >> 3) & 1): lanes l and l + 4 of a ds_write_b128 pass would otherwise meet in the
+                // same four banks — 2.1e7 conflict cycles per launch, SQ_LDS_BANK_CONFLICT; reads permute inside aligned groups of 8)
+                const uint32_t wsw = (lane >> 2) & 1u, rsw = lane ^ ((lane >> 3) & 1u);
+                xpose[(2u * lane) ^ wsw] = make_uint4(o[0], o[1], o[2], o[3]);
+                xpose[(2u * lane + 1u) ^ wsw] = make_uint4(o[4], o[5], o[6], o[7]);
                 wave_lds_fence();
-                const uint4 v0 = xpose[lane], v1 = xpose[64u + lane];
+                const uint4 v0 = xpose[rsw], v1 = xpose[64u + rsw];
                 wave_lds_fence();
                 uint4 *op = pcm_half + ((uint32_t)j * 128u + lane);
                 op[0] = v0;

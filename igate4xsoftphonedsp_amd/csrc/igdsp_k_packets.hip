@@ -218,6 +218,8 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
             {
                 const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kRtpRow);       // 112-byte rows, 16-byte aligned
                 const uint4 h = row[0];                   // {size word | 0, RTP bytes 0-3, ext profile/length, ED-137 word}
+                if (!SLOT) asm volatile("" ::"v"(h.x));     // packed: h.x is unused, and without this the row is fetched as eleven dword PAIRS starting at
+                                                          // dword 1 (ds_read2_b32: 4-way bank conflicts at the 112-byte row stride) instead of six ds_read_b128
                 uint64_t s = 0;
                 uint32_t peak = 0, bsum = 0, fail = 0;
 #pragma unroll
