@@ -81,6 +81,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xFFFFFFFFu, 0x00020000);
 }
+// the same with a range: raw buffer accesses at an offset >= bytes are dropped by the hardware (stores) / return zero (loads),
+// which lets a lane opt out of a store without a branch
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_ranged(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
 __device__ __forceinline__ uint4 buf_ld_stream(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 2);          // aux 2 = nt

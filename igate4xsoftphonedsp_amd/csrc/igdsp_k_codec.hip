@@ -734,21 +734,21 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
     const uint32_t T = (n - 16u * Q) >> 2;
     constexpr int kPk = (QP + 1) / 2;
     uint32_t pk[kPk];
-#pragma unroll
+    uint32_t po[QP];                                             // byte offset of this lane's piece j inside a 64-channel frame row (registers:
+#pragma unroll                                                   // recomputing f * n + ... per use cost two quarter-rate multiplies per piece)
     for (int j = 0; j < kPk; ++j) pk[j] = 0;
 #pragma unroll
     for (int j = 0; j < QP; ++j) {
         const uint32_t p = (uint32_t)j * 64u + lane, f = p / (uint32_t)QP, q = p - f * (uint32_t)QP;
         const uint32_t sh = q == 1u ? 0u : (q == 3u ? 8u : (q == 2u ? 16u : 24u));
-        pk[j >> 1] |= (f | (((TAIL && q == (uint32_t)Q) ? 24u : sh) << 8) | ((TAIL && q == (uint32_t)Q) ? 0x2000u : 0u)) << (16 * (j & 1));
+        const bool tp = TAIL && q == (uint32_t)Q;
+        pk[j >> 1] |= (f | ((tp ? 24u : sh) << 8) | (tp ? 0x2000u : 0u)) << (16 * (j & 1));
+        po[j] = f * n + (tp ? n - 16u : 16u * q);
     }
     auto fr_of = [&](int j) { return __builtin_amdgcn_ubfe(pk[j >> 1], 16 * (j & 1), 6); };
     auto ps_of = [&](int j) { return __builtin_amdgcn_ubfe(pk[j >> 1], 16 * (j & 1) + 8, 5); };
     auto tail_of = [&](int j) { return TAIL && ((pk[j >> 1] >> (16 * (j & 1) + 13)) & 1u) != 0u; };
-    auto po_of = [&](int j) {                                    // byte offset of this lane's piece j inside a 64-channel frame row
-        const uint32_t f = fr_of(j), q = (uint32_t)j * 64u + lane - f * (uint32_t)QP;
-        return f * n + (tail_of(j) ? n - 16u : 16u * q);
-    };
+    auto po_of = [&](int j) { return po[j]; };
     const uint32_t total_waves = gridDim.x * kRtlWaves;
     const uint64_t fbytes = (uint64_t)C * n;                       // bytes between two frames of one channel group
 
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
         for (uint32_t f = f_lo; f < f_hi; ++f) {
             const bool more = f + 1u < f_hi;
             const __amdgpu_buffer_rsrc_t rin = make_rsrc(in0 + (uint64_t)(more ? f + 1u : f) * fbytes);
-            const __amdgpu_buffer_rsrc_t rout = make_rsrc(out0 + (uint64_t)f * fbytes);
+            const __amdgpu_buffer_rsrc_t rout = make_rsrc_ranged(out0 + (uint64_t)f * fbytes, (uint32_t)kSuperFrames * n);   // this group's 64 frames of the row
 #pragma unroll
             for (int j = 0; j < kPk; ++j) asm volatile("" : "+v"(pk[j]));
             {
@@ -819,12 +819,16 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
                     if (k == 1) {
                         uint2 ent = make_uint2(sum, (peak >> 16) | (bsum << 16) | probe_fail(d[j], 0xFFu << ps_of(j)));
                         const uint32_t pj = po_of(j);
-                        if (tail_of(j)) {
-                            ent = make_uint2(d[j].z, d[j].w);                   // the frame's last two dwords, raw, for the frame lane
-                            const uint32_t to = fr_of(j) * n + 16u * Q;         // the tail's re-encoded bytes go right behind piece Q - 1
+                        // no branch on the per-lane tail flag: every lane issues both stores, the one that does not apply at an offset past
+                        // the frame row's buffer range (raw buffer stores out of range are dropped by the hardware)
+                        const bool tl = tail_of(j);
+                        if (tl) ent = make_uint2(d[j].z, d[j].w);               // the frame's last two dwords, raw, for the frame lane
+                        buf_st(rout, tl ? 0x80000000u : pj, 0u, make_uint4(o[0], o[1], o[2], o[3]));
+                        if (TAIL) {
+                            const uint32_t to = tl ? pj + 16u - 4u * T : 0x80000000u;   // the tail's re-encoded bytes go right behind piece Q - 1
                             if (T == 2u) { u32x2_t v; v.x = o[2]; v.y = o[3]; __builtin_amdgcn_raw_buffer_store_b64(v, rout, (int)to, 0, 0); }
                             else __builtin_amdgcn_raw_buffer_store_b32(o[3], rout, (int)to, 0, 0);
-                        } else buf_st(rout, pj, 0u, make_uint4(o[0], o[1], o[2], o[3]));
+                        }
                         strip[j * 64 + lane] = ent;
                         d[j] = buf_ld_stream(rin, pj, 0u);
                         sum = 0; peak = 0; bsum = 0;
