@@ -539,10 +539,12 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
                 };
                 int verdict = -1;
                 bool have_src = false;
-                for (size_t st = 1; st <= 3 && ok && verdict != 0; ++st) {    // ten consecutive pool chunks, then every 2nd, every 3rd
+                // candidate sources: ten consecutive pool chunks from the start, every 2nd, every 3rd, then consecutive windows further in
+                const size_t picks[][2] = {{0, 1}, {0, 2}, {0, 3}, {kSrcChunks, 1}, {2 * kSrcChunks, 1}, {3 * kSrcChunks, 1}, {1, 2}};
+                for (size_t pi = 0; pi < sizeof(picks) / sizeof(picks[0]) && ok && verdict != 0; ++pi) {
                     std::vector<size_t> sb;
-                    for (size_t k = 0; k < poolB.size() && sb.size() < kSrcChunks; k += st) sb.push_back(poolB[k]);
-                    if (sb.size() < kSrcChunks) break;
+                    for (size_t k = picks[pi][0]; k < poolB.size() && sb.size() < kSrcChunks; k += picks[pi][1]) sb.push_back(poolB[k]);
+                    if (sb.size() < kSrcChunks) continue;
                     for (int tries = 0; ok; ++tries) {
                         verdict = try_source(sb);
                         have_src = true;

@@ -29,6 +29,8 @@ B = 65536 * 128
 SHAPES = {"store160": (B * 160, B * 16, B * 320), "store164": (B * 164, B * 16, B * 328), "roundtrip": (B * 160, B * 16, B * 160),
           "encode": (B * 320, B * 16, B * 160), "store80": (B * 80, B * 16, B * 160), "store240": (B * 240, B * 16, B * 480)}
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+if len(sys.argv) > 2:
+    SHAPES = {k: v for k, v in SHAPES.items() if k in sys.argv[2:]}
 os.makedirs(os.path.join(ROOT, "gpurun_out", "io_soak"), exist_ok=True)
 for r in range(runs):
     for name, (a, b, c) in SHAPES.items():
