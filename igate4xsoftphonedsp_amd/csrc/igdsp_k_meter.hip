@@ -704,7 +704,7 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
     constexpr int kWaves = StridedGeom<QP, STORE>::kWaves;
     constexpr int kRow = QP | 1;                                 // strip row of a frame: an ODD number of 8-byte entries, so the fold's ds_read_b64 meet no bank twice
     constexpr int kStrip = kSuperFrames * kRow;                  // (rows of 8 entries = 16 banks put lanes l, l + 2, ... on the same banks: 8-way conflicts at n = 128)
-    constexpr int kLutU2 = STORE ? kLutEntries : kLut32Words / 2;   // records only: the 4-byte m * m table (32 KiB, igdsp_device.h); with PCM the 8-byte one
+    constexpr int kLutU2 = STORE ? kLutEntries : kLut32Words / 2;   // records only: the 4-byte m * m table (64 KiB as well: 256 raw-byte rows, igdsp_device.h); with PCM the 8-byte one
     __shared__ uint2 lds[kLutU2 + kWaves * kStrip + (STORE ? kWaves * 256 : 0)];        // LUT, strips (+ 2 KiB PCM transposition scratch per wave)
     __shared__ BlockQueue<kWaves> bq;
     __shared__ AggBlock aggb;

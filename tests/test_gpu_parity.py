@@ -133,6 +133,27 @@ def test_other_frame_sizes_image_kernel(ctx, orc, n, ragged):
     assert agg["peak_slot"].tolist() == eagg["peak_slot"].tolist()
 
 
+@pytest.mark.parametrize("n", [164, 24, 240, 128])
+def test_strided_peak_is_exact_for_every_code(ctx, orc, n):
+    """The record-only k_meter_strided kernels look up (|x| / 4)^2 alone and recover the peak as the integer root of the largest
+    square of a 16-sample piece (one v_sqrt_f32, isqrt_m2).  Every G.711 magnitude of both laws has to come back exactly:
+    frame c of a launch holds code c in every byte (so its peak is |decode(c)|, in the pieces and in the tail dwords), plus
+    frames with ONE loud sample at every position of a piece among quiet ones.  Records against the oracle."""
+    C_, F_ = 256, 3
+    payload = np.empty((F_, C_, n), dtype=np.uint8)
+    payload[0] = np.arange(256, dtype=np.uint8)[:, None]                     # frame c: all bytes = c
+    payload[1] = 0xFF                                                        # quiet frames with one loud sample each
+    payload[2] = 0xD5
+    for c in range(C_):
+        payload[1, c, (c * 7) % n] = c
+        payload[2, c, n - 1 - (c * 5) % n] = c
+    for law in (0, 8):
+        codec = np.full((C_,), law, dtype=np.uint8)
+        st, _, _ = gu.run_decode_meter(ctx, payload, codec)
+        est = orc.decode_meter(payload, codec)
+        gu.assert_stats_equal(st, est, n=n)
+
+
 @pytest.mark.parametrize("n", [160, 164, 80])
 def test_dword_aligned_payload_keeps_the_chunk_pipeline(ctx, orc, n):
     """A payload buffer that is only dword aligned (base + 4) cannot take the 16-byte aligned loads of k_meter_chunk64 /
