@@ -374,7 +374,9 @@ int igdsp_roundtrip_peakhold(igdsp_ctx *ctx, const uint8_t *d_payload, const uin
     // every shape is served: whole groups of 64 channels of 160-byte frames by the fused channel-group-major kernel,
     // the remaining channels and every other geometry by the general wave-per-channel kernel (launch_roundtrip)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_roundtrip(cfg_of(ctx), ctx->variant, d_payload, d_codec, C, F, n, d_out, d_stats, d_hold, d_gate, variant, pick(ctx, stream)));
+    igdsp::LaunchCfg cfg = cfg_of(ctx);
+    cfg.out_spread = ctx->is_spread(d_out);
+    HIP_TRY(ctx, launch_roundtrip(cfg, ctx->variant, d_payload, d_codec, C, F, n, d_out, d_stats, d_hold, d_gate, variant, pick(ctx, stream)));
     return IGDSP_OK;
 }
 

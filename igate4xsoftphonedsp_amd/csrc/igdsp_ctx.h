@@ -26,6 +26,18 @@ struct igdsp_ctx {
     int variant = 0;
     std::string err;
 
+    // bulk output buffers handed out by igdsp_io_alloc with their halves in two memory classes: a kernel that writes one may
+    // pick the traversal that suits that placement (launch_roundtrip)
+    struct IoRange { const char *base; size_t bytes; };
+    std::vector<IoRange> spread_ranges;
+    std::mutex io_mu;
+    bool is_spread(const void *p)
+    {
+        std::lock_guard<std::mutex> g(io_mu);
+        for (const auto &r : spread_ranges) if ((const char *)p >= r.base && (const char *)p < r.base + r.bytes) return true;
+        return false;
+    }
+
     // a4 routing: direct table for 0 <= call_id < 65536 (lock-free reads), map beyond
     std::vector<std::atomic<uint32_t>> direct;
     std::unordered_map<int32_t, uint32_t> far;

@@ -22,6 +22,7 @@ struct LaunchCfg {
     int compute_units;   // persistent grid = compute_units blocks
     uint32_t *gqueue;    // device-wide work counter {next batch, blocks done} for this launch, zero on entry
                          // and re-armed by the kernel itself; nullptr = static per-block distribution
+    bool out_spread = false;   // the launch's bulk output sits half in one, half in another memory class (igdsp_io_alloc)
 };
 
 hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant,

@@ -184,6 +184,12 @@ int igdsp_io_free(igdsp_ctx *ctx, igdsp_io_set *set)
     // gfx950) an address that has been un-mapped — even freed and reserved again — and is then mapped onto another chunk keeps
     // reaching the old one (igdsp_internal_vmm_remap_check; tools/io_place.py prints it), so no address is ever handed back for
     // re-use.  Address space is the only thing this costs (<= ~0.2 TiB of 128 TiB per igdsp_io_alloc call).
+    {
+        std::lock_guard<std::mutex> g(ctx->io_mu);
+        for (auto &m : set->maps)
+            for (size_t k = 0; k < ctx->spread_ranges.size();)
+                if (ctx->spread_ranges[k].base == (const char *)m.va) ctx->spread_ranges.erase(ctx->spread_ranges.begin() + (long)k); else ++k;
+    }
     for (auto &m : set->maps) {
         if (!m.va) continue;
         for (size_t i = 0; i < m.handles.size(); ++i) (void)hipMemUnmap((char *)m.va + i * set->chunk, set->chunk);
@@ -690,6 +696,11 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
             if (bufs[i].role == role && set->maps[i].handles.size() < nch[i]) ok = map_fresh(i);
     if (!ok) { (void)hipGetLastError(); return finish(fail(ctx, IGDSP_ENOMEM, "igdsp_io_alloc: mapping chunks")); }
     for (uint32_t i = 0; i < n_bufs; ++i) bufs[i].ptr = set->maps[i].va;
+    if (R.bulk_spread) {
+        std::lock_guard<std::mutex> g(ctx->io_mu);
+        for (uint32_t i = 0; i < n_bufs; ++i)
+            if (bufs[i].role == IGDSP_IO_BULK) ctx->spread_ranges.push_back({(const char *)set->maps[i].va, set->maps[i].bytes});
+    }
     if (const char *e = std::getenv("IGDSP_IO_SETTLE")) if (std::atoi(e) == 0) t_ref = 0.f;
     if (t_ref > 0.f) {
         Explorer Y;

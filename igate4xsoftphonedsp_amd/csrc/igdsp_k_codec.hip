@@ -634,10 +634,17 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_lut64(
     const uint32_t total_waves = gridDim.x * kRtlWaves;
     const uint64_t fbytes = (uint64_t)C * kFrame;                  // bytes between two frames of one channel group
 
-    // order 0: the waves of a block take items a grid apart (neighbouring BLOCKS touch neighbouring groups); order 1: the
-    // waves of a block take consecutive items (one block touches kRtlWaves neighbouring groups = 120 KiB per frame)
-    const uint32_t first = order ? blockIdx.x * (uint32_t)kRtlWaves + wave : wave * gridDim.x + blockIdx.x;
-    for (uint32_t item = first; item < n_groups * n_seg; item += total_waves) {
+    // order 0: the waves of a block take items a grid apart (neighbouring BLOCKS touch neighbouring groups); order 1 (default):
+    // in the FIRST round the waves of a block take consecutive items (one block touches kRtlWaves neighbouring groups = 120 KiB
+    // per frame: 0.4695 vs 0.4756 ms in an alternating in-process A/B, tools/rt_knobs.py); later rounds — the remainder when the
+    // item count is not a multiple of the wave count — always go a grid apart, which spreads them evenly over the CUs (with
+    // consecutive items there, a few blocks got all of the remainder: 0.5745 ms at four segments).
+    const uint32_t n_items = n_groups * n_seg;
+    const uint32_t near = blockIdx.x * (uint32_t)kRtlWaves + wave, apart = wave * gridDim.x + blockIdx.x;
+    for (uint32_t round = 0;; ++round) {
+        const uint64_t item64 = (uint64_t)round * total_waves + ((order && round == 0u) ? near : apart);
+        if (item64 >= n_items) { if ((uint64_t)round * total_waves >= n_items) break; else continue; }
+        const uint32_t item = (uint32_t)item64;
         const uint32_t seg = item / n_groups, cg = item - seg * n_groups;
         const uint32_t f_lo = (uint32_t)(((uint64_t)F * seg) / n_seg), f_hi = (uint32_t)(((uint64_t)F * (seg + 1u)) / n_seg);
         if (f_lo >= f_hi) continue;
@@ -1129,8 +1136,10 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
         if (const char *e = std::getenv("IGDSP_RT_NSEG")) n_seg = (uint32_t)std::max(1, std::atoi(e));   // experiments
         n_seg = std::max(1u, std::min(n_seg, std::max(1u, F / 8u)));
         n_seg = std::max(n_seg, F / 65535u + 1u);               // the fused kernels count silent / clipped frames of a segment in 16 bits
-        uint32_t order = 0;
-        if (const char *e = std::getenv("IGDSP_RT_ORDER")) order = (uint32_t)std::atoi(e);
+        // consecutive groups per block pay when the output's halves lie in two memory classes (0.4695 vs 0.4756 ms); with the whole
+        // output in one class it is the other way round (0.5116 vs 0.4920 ms): tools/rt_knobs.py, alternating in one process
+        uint32_t order = cfg.out_spread ? 1u : 0u;
+        if (const char *e = std::getenv("IGDSP_RT_ORDER")) order = (uint32_t)std::atoi(e);   // experiments
         const uint32_t grid = blocks_for((uint64_t)n_groups * n_seg, waves, (uint32_t)cfg.compute_units);
         if (kernel_variant == 4) {
             if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_G191>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);

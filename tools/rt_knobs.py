@@ -38,9 +38,16 @@ b = min(bare() for _ in range(3))
 print(f"bare 1:1 stream on these buffers: {b:.4f} ms  {2 * B / b / 1e6:.0f} GB/s", flush=True)
 ctx.set_variant(4); ms(10); v4 = min(ms() for _ in range(3)); ctx.set_variant(0)
 print(f"cell-table form (variant 4): {v4:.4f} ms", flush=True)
-for order in (0,):
-    for nseg in (2, 3, 4, 5, 6, 8):
+for order in (0, 1):
+    for nseg in (2, 3, 4, 6):
         os.environ["IGDSP_RT_ORDER"] = str(order); os.environ["IGDSP_RT_NSEG"] = str(nseg)
         ms(10)
         v = min(ms() for _ in range(3))
         print(f"order {order} n_seg {nseg:2d}: {v:.4f} ms  {B * 2.10625 / v / 1e6:.0f} GB/s", flush=True)
+os.environ.pop("IGDSP_RT_NSEG")
+for rep in range(4):                                   # A/B of the default segment count under both orders, alternating
+    for order in (0, 1):
+        os.environ["IGDSP_RT_ORDER"] = str(order)
+        ms(10)
+        v = min(ms() for _ in range(3))
+        print(f"A/B {rep}: order {order}: {v:.4f} ms  frac {B * 2.10625 / v / 1e6 / 8000:.4f}", flush=True)
