@@ -724,7 +724,7 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
     // piece << 13, in each 16-bit half.  The byte offset of piece j inside the item follows from the frame and the piece
     // number: f * n + (tail ? n - 16 : 16 q).
     constexpr int kPk = (QP + 1) / 2;
-    constexpr bool kPoRegs = !STORE;                             // records only: the piece offsets stay in registers (the 4-byte LUT leaves room)
+    constexpr bool kPoRegs = !STORE || QP <= 11;                 // the piece offsets stay in registers where they fit (with PCM at 15 pieces they do not)
     uint32_t pk[kPk];
     uint32_t po[kPoRegs ? QP : 1];
 #pragma unroll
@@ -774,9 +774,7 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
             const bool has_next = s_next < n_super;
             const uint32_t s_load = has_next ? s_next : 0u;      // last round: re-read item 0 (L2-hot), loads stay unconditional
             const uint32_t f0 = sidx * kSuperFrames;
-            const bool my_alaw = cur_pt == IGDSP_PT_PCMA;
-            const uint64_t amask = __ballot(my_alaw);
-            const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
+            const bool my_alaw = cur_pt == IGDSP_PT_PCMA;          // lane = frame; the pieces fetch it from here with ds_bpermute
             const uint8_t *nbase = payload + (uint64_t)s_load * item_bytes;
             const uint32_t nxt_pt = fetch_pt(s_load);
 #pragma unroll
@@ -784,16 +782,14 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
             {
                 uint2 e[2][8];
                 uint32_t wa[2], wb[2];
-                uint32_t oj = off;
-                const uint32_t law_off = my_alaw ? 0x80u : 0u;
+                uint32_t oj = off, lmj = 0;
+                const uint32_t law_off = my_alaw ? 0x80u : 0u, law_mask = my_alaw ? 0x80808080u : 0u;
                 auto issue = [&](int u) {
                     const int j = u >> 1, k = u & 1;
                     wa[k] = (u & 1) ? d[j].z : d[j].x;
                     wb[k] = (u & 1) ? d[j].w : d[j].y;
                     if (STORE) {
-                        const uint32_t frj = fr_of(j);
-                        const uint32_t bit = frj < 32u ? (uint32_t)__builtin_amdgcn_sbfe(am_lo, frj, 1) : (uint32_t)__builtin_amdgcn_sbfe(am_hi, frj - 32u, 1);
-                        const uint32_t lmj = bit & 0x80808080u;
+                        if (k == 0) lmj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)fr4_of(j), (int)law_mask);   // the law of this piece's frame, from the frame's own lane
                         const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lmj, tb = (wb[k] & 0x7F7F7F7Fu) | lmj;
                         e[k][0] = lut_at(lds, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lds, ta, off, 0x0C0C0500u);
                         e[k][2] = lut_at(lds, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lds, ta, off, 0x0C0C0700u);
