@@ -347,7 +347,11 @@ __global__ __launch_bounds__(kDpWaves * 64, 3) void k_depayload64(const uint8_t 
     uint4 *hw = hdrs[wave];
     const uint32_t n_super = n_frames / kSuperFrames;
     const uint32_t total_waves = gridDim.x * kDpWaves;
-    for (uint32_t sidx = blockIdx.x * kDpWaves + wave; sidx < n_super; sidx += total_waves) {
+    for (uint32_t it = blockIdx.x * kDpWaves + wave; it < n_super; it += total_waves) {
+        // items are visited alternately from the two halves of the launch, so that the dense output's two halves — which
+        // igdsp_io_alloc puts into two memory classes — are both being written at any moment (as spread_batch does for the
+        // persistent kernels)
+        const uint32_t sidx = spread_batch(it, n_super);
         // piece p = j * 64 + lane of the item -> packet fr = p / 12, piece q = p % 12.  Recomputed from an opaque copy of
         // the lane id in each phase: hoisting all 12 x 3 sets of lane constants out of the loop costs more registers
         // (and spills) than the few VALU ops they take.
