@@ -726,7 +726,7 @@ template <int Q, bool TAIL, int VARIANT>
 __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
     const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F, uint32_t n,
     uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats, igdsp_chan_hold *__restrict__ hold,
-    const uint8_t *__restrict__ gate, uint32_t n_seg, uint32_t n_groups)
+    const uint8_t *__restrict__ gate, uint32_t n_seg, uint32_t n_groups, uint32_t order)
 {
     static_assert(Q == 1 || Q >= 4, "the probe bytes 28 / 38 / 48 are taken from pieces 1 / 2 / 3");
     constexpr int QP = Q + (TAIL ? 1 : 0);
@@ -759,7 +759,13 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
     const uint32_t total_waves = gridDim.x * kRtlWaves;
     const uint64_t fbytes = (uint64_t)C * n;                       // bytes between two frames of one channel group
 
-    for (uint32_t item = wave * gridDim.x + blockIdx.x; item < n_groups * n_seg; item += total_waves) {
+    // item order as in k_roundtrip_lut64: consecutive groups per block in the first round when the output is spread over two classes
+    const uint32_t n_items = n_groups * n_seg;
+    const uint32_t near = blockIdx.x * (uint32_t)kRtlWaves + wave, apart = wave * gridDim.x + blockIdx.x;
+    for (uint32_t round = 0;; ++round) {
+        const uint64_t item64 = (uint64_t)round * total_waves + ((order && round == 0u) ? near : apart);
+        if (item64 >= n_items) { if ((uint64_t)round * total_waves >= n_items) break; else continue; }
+        const uint32_t item = (uint32_t)item64;
         const uint32_t seg = item / n_groups, cg = item - seg * n_groups;
         const uint32_t f_lo = (uint32_t)(((uint64_t)F * seg) / n_seg), f_hi = (uint32_t)(((uint64_t)F * (seg + 1u)) / n_seg);
         if (f_lo >= f_hi) continue;
@@ -1112,8 +1118,8 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
         const dim3 g3(grid), b3(kRtlWaves * 64);
 #define IGDSP_RTS(QV, TV)                                                                                                                                      \
         if (Qn == QV && (Tn != 0u) == TV) {                                                                                                                     \
-            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_G191>), g3, b3, 0, s, payload, codec, C, F, n, out, stats, hold, gate, n_seg, n_groups_s);  \
-            else                           hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_SUN16>), g3, b3, 0, s, payload, codec, C, F, n, out, stats, hold, gate, n_seg, n_groups_s); \
+            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_G191>), g3, b3, 0, s, payload, codec, C, F, n, out, stats, hold, gate, n_seg, n_groups_s, cfg.out_spread ? 1u : 0u);  \
+            else                           hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_SUN16>), g3, b3, 0, s, payload, codec, C, F, n, out, stats, hold, gate, n_seg, n_groups_s, cfg.out_spread ? 1u : 0u); \
         }
         IGDSP_RTS(1, true) IGDSP_RTS(5, false) IGDSP_RTS(10, true) IGDSP_RTS(15, false)
 #undef IGDSP_RTS
