@@ -758,21 +758,33 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
     // with a bulk output (PCM) the two halves of the batch range are visited alternately, as in k_meter_chunk64: igdsp_io_alloc
     // spreads a bulk buffer's halves over two memory classes and the writes should reach both at any moment
     const uint32_t n_batches = STORE ? (n_super + (uint32_t)kWaves - 1u) / (uint32_t)kWaves : 0u;
-    auto grab = [&]() { return bq_grab(bq, gqueue, G, lane, n_batches); };
+    // A queue slot stands for kPerSlot CONSECUTIVE items when items are small: the device-wide queue costs one device atomic
+    // (~2 us of latency, prefetched one batch ahead) per batch of kWaves slots, and with 1.5-5 KiB items that atomic rate, not
+    // the memory system, bounded the launch (n = 24: 0.39 of peak with one item per slot, 0.63 with a static schedule).
+    constexpr uint32_t kPerSlot = STORE ? 1u : (QP <= 2 ? 8u : (QP <= 7 ? 2u : 1u));
+    uint32_t g_slot = spread_batch(blockIdx.x, n_batches) * (uint32_t)kWaves + wave, g_k = 0;     // the wave's first slot is static
+    auto grab = [&]() -> uint32_t {                              // next item id of this wave (>= n_super: none left)
+        if (kPerSlot > 1u && g_k + 1u < kPerSlot && g_slot != 0xFFFFFFFFu) { ++g_k; return g_slot * kPerSlot + g_k; }
+        const uint32_t n_slots = (n_super + kPerSlot - 1u) / kPerSlot;
+        g_slot = bq_grab(bq, gqueue, G, lane, n_batches);
+        g_k = 0;
+        if (g_slot >= n_slots) { g_slot = 0xFFFFFFFFu; return 0xFFFFFFFFu; }
+        return g_slot * kPerSlot;
+    };
 
-    uint32_t sidx = spread_batch(blockIdx.x, n_batches) * (uint32_t)kWaves + wave;
-    if (sidx < n_super) {
-        uint4 d[QP];
-        uint32_t cur_pt = fetch_pt(sidx);
-        {
-            const uint8_t *b0 = payload + (uint64_t)sidx * item_bytes;
-#pragma unroll
-            for (int j = 0; j < QP; ++j) d[j] = ld16_dw(b0 + po_of(j));
-        }
-        uint32_t s_next = grab();
-        for (;;) {
-            const bool has_next = s_next < n_super;
-            const uint32_t s_load = has_next ? s_next : 0u;      // last round: re-read item 0 (L2-hot), loads stay unconditional
+    // Lookahead: at 16 - 24 bytes per frame an item is 1 - 1.5 KiB and ONE item of loads in flight per wave does not cover the
+    // memory latency (16 waves x 1.5 KiB = 24 KiB per CU at n = 24, against ~150 KiB for n >= 160).  The record-only kernels for
+    // those sizes keep TWO items in registers: while item i is expanded out of A (its registers refilled from item i + 2), item
+    // i + 1 is already in flight into B (n = 24: 0.58 -> 0.60 of peak).  From four pieces per frame on it does not pay any more
+    // (n = 64 / 80 / 96: 0.79 / 0.78 / 0.78 with one item ahead, 0.77 / 0.77 / 0.76 with two).
+    constexpr bool kTwoAhead = !STORE && QP <= 2;
+    const uint32_t sidx0 = g_slot * kPerSlot;                    // item 0 of the wave's first slot
+    if (sidx0 < n_super) {
+        // One item: expand it out of d (item sidx, codec id cur_pt of this lane's frame), re-load every piece register from item s_load
+        // the moment it has been folded (s_load = 0 past the end: item 0 is L2-hot and the loads stay unconditional), draw one more
+        // item id when asked (its LDS round trip hides under the fold); returns the codec id of this lane's frame in item s_load.
+        auto step = [&](uint4 (&d)[QP], const uint32_t sidx, const uint32_t cur_pt, const uint32_t s_load, const bool do_grab,
+                        uint32_t &s_after) __attribute__((always_inline)) -> uint32_t {
             const uint32_t f0 = sidx * kSuperFrames;
             const bool my_alaw = cur_pt == IGDSP_PT_PCMA;          // lane = frame; the pieces fetch it from here with ds_bpermute
             const uint8_t *nbase = payload + (uint64_t)s_load * item_bytes;
@@ -869,7 +881,7 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
                     }
                 }
             }
-            const uint32_t s_after = has_next ? grab() : 0xFFFFFFFFu;
+            s_after = do_grab ? grab() : 0xFFFFFFFFu;
             wave_lds_fence();
             {
                 const uint2 *row = strip + lane * kRow;            // the pieces of this lane's frame
@@ -921,10 +933,46 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
                 }
             }
             wave_lds_fence();
-            if (!has_next) break;
-            sidx = s_next;
-            s_next = s_after;
-            cur_pt = nxt_pt;
+            return nxt_pt;
+        };
+        auto load_item = [&](uint4 (&d)[QP], const uint32_t s) __attribute__((always_inline)) {
+            const uint8_t *b0 = payload + (uint64_t)s * item_bytes;
+#pragma unroll
+            for (int j = 0; j < QP; ++j) d[j] = ld16_dw(b0 + po_of(j));
+        };
+        if (!kTwoAhead) {
+            uint4 d[QP];
+            uint32_t sidx = sidx0, cur_pt = fetch_pt(sidx);
+            load_item(d, sidx);
+            uint32_t s_next = grab();
+            for (;;) {
+                const bool has_next = s_next < n_super;
+                uint32_t s_after;
+                const uint32_t nxt_pt = step(d, sidx, cur_pt, has_next ? s_next : 0u, has_next, s_after);
+                if (!has_next) break;
+                sidx = s_next;
+                s_next = s_after;
+                cur_pt = nxt_pt;
+            }
+        } else {
+            uint4 A[QP], B[QP];
+            uint32_t x0 = sidx0, p0 = fetch_pt(x0);
+            load_item(A, x0);
+            uint32_t x1 = grab();
+            bool v1 = x1 < n_super;
+            uint32_t p1 = fetch_pt(v1 ? x1 : 0u);
+            load_item(B, v1 ? x1 : 0u);
+            uint32_t x2 = v1 ? grab() : 0xFFFFFFFFu;
+            for (;;) {
+                const bool v2 = x2 < n_super;
+                uint32_t x3, x4;
+                const uint32_t p2 = step(A, x0, p0, v2 ? x2 : 0u, v2, x3);      // item x0 out of A; A refilled from x2; x3 drawn
+                if (!v1) break;
+                const bool v3 = x3 < n_super;
+                const uint32_t p3 = step(B, x1, p1, v3 ? x3 : 0u, v3, x4);      // item x1 out of B; B refilled from x3; x4 drawn
+                if (!v2) break;
+                x0 = x2; p0 = p2; x1 = x3; p1 = p3; v1 = v3; x2 = x4;
+            }
         }
     }
     wave_exit(AGG ? agg : nullptr, rank, aggb, (uint32_t)kWaves, lane, gqueue, G, a_sumsq, lane == 0u ? (uint64_t)u_frames * n : 0ull,
