@@ -755,17 +755,17 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
     uint32_t a_bm = 0, a_peak = 0;
     uint32_t u_frames = 0, u_sil = 0, u_clip = 0;
     auto fetch_pt = [&](uint32_t sidx) { return (uint32_t)codec[(sidx * (uint32_t)kSuperFrames + lane) % C]; };
-    // with a bulk output (PCM) the two halves of the batch range are visited alternately, as in k_meter_chunk64: igdsp_io_alloc
-    // spreads a bulk buffer's halves over two memory classes and the writes should reach both at any moment
-    const uint32_t n_batches = STORE ? (n_super + (uint32_t)kWaves - 1u) / (uint32_t)kWaves : 0u;
     // A queue slot stands for kPerSlot CONSECUTIVE items when items are small: the device-wide queue costs one device atomic
     // (~2 us of latency, prefetched one batch ahead) per batch of kWaves slots, and with 1.5-5 KiB items that atomic rate, not
     // the memory system, bounded the launch (n = 24: 0.39 of peak with one item per slot, 0.63 with a static schedule).
-    constexpr uint32_t kPerSlot = STORE ? 1u : (QP <= 2 ? 8u : (QP <= 7 ? 2u : 1u));
+    constexpr uint32_t kPerSlot = STORE ? 1u : (QP <= 2 ? 8u : (QP <= 7 ? 2u : 1u));   // (with PCM the stores bound the launch: no gain measured)
+    const uint32_t n_slots = (n_super + kPerSlot - 1u) / kPerSlot;
+    // with a bulk output (PCM) the two halves of the batch range are visited alternately, as in k_meter_chunk64: igdsp_io_alloc
+    // spreads a bulk buffer's halves over two memory classes and the writes should reach both at any moment (a batch = kWaves slots)
+    const uint32_t n_batches = STORE ? (n_slots + (uint32_t)kWaves - 1u) / (uint32_t)kWaves : 0u;
     uint32_t g_slot = spread_batch(blockIdx.x, n_batches) * (uint32_t)kWaves + wave, g_k = 0;     // the wave's first slot is static
     auto grab = [&]() -> uint32_t {                              // next item id of this wave (>= n_super: none left)
         if (kPerSlot > 1u && g_k + 1u < kPerSlot && g_slot != 0xFFFFFFFFu) { ++g_k; return g_slot * kPerSlot + g_k; }
-        const uint32_t n_slots = (n_super + kPerSlot - 1u) / kPerSlot;
         g_slot = bq_grab(bq, gqueue, G, lane, n_batches);
         g_k = 0;
         if (g_slot >= n_slots) { g_slot = 0xFFFFFFFFu; return 0xFFFFFFFFu; }
