@@ -1098,6 +1098,11 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
                             const uint8_t *gate, int variant, hipStream_t s)
 {
     if ((uint64_t)C * F == 0) return hipSuccess;
+    // Item order of the fused kernels.  Consecutive groups per block pay when the output's halves lie in two memory classes
+    // (0.4695 vs 0.4756 ms); with the whole output in one class it is the other way round (0.5116 vs 0.4920 ms): tools/rt_knobs.py,
+    // alternating in one process.  IGDSP_RT_ORDER overrides (experiments, and the test of the order the placement would pick).
+    uint32_t order = cfg.out_spread ? 1u : 0u;
+    if (const char *e = std::getenv("IGDSP_RT_ORDER")) order = (uint32_t)std::atoi(e);
     // The fused channel-group-major kernels take whole groups of 64 channels of 160-byte frames in 16-byte aligned
     // buffers; the C % 64 channels left over, and every other shape (n != 160, unaligned buffers), go through
     // k_roundtrip_general on the same stream.  kernel_variant 4 selects the compressor-cell-table form of the fused
@@ -1118,8 +1123,8 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
         const dim3 g3(grid), b3(kRtlWaves * 64);
 #define IGDSP_RTS(QV, TV)                                                                                                                                      \
         if (Qn == QV && (Tn != 0u) == TV) {                                                                                                                     \
-            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_G191>), g3, b3, 0, s, payload, codec, C, F, n, out, stats, hold, gate, n_seg, n_groups_s, cfg.out_spread ? 1u : 0u);  \
-            else                           hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_SUN16>), g3, b3, 0, s, payload, codec, C, F, n, out, stats, hold, gate, n_seg, n_groups_s, cfg.out_spread ? 1u : 0u); \
+            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_G191>), g3, b3, 0, s, payload, codec, C, F, n, out, stats, hold, gate, n_seg, n_groups_s, order);  \
+            else                           hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_SUN16>), g3, b3, 0, s, payload, codec, C, F, n, out, stats, hold, gate, n_seg, n_groups_s, order); \
         }
         IGDSP_RTS(1, true) IGDSP_RTS(5, false) IGDSP_RTS(10, true) IGDSP_RTS(15, false)
 #undef IGDSP_RTS
@@ -1142,10 +1147,6 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
         if (const char *e = std::getenv("IGDSP_RT_NSEG")) n_seg = (uint32_t)std::max(1, std::atoi(e));   // experiments
         n_seg = std::max(1u, std::min(n_seg, std::max(1u, F / 8u)));
         n_seg = std::max(n_seg, F / 65535u + 1u);               // the fused kernels count silent / clipped frames of a segment in 16 bits
-        // consecutive groups per block pay when the output's halves lie in two memory classes (0.4695 vs 0.4756 ms); with the whole
-        // output in one class it is the other way round (0.5116 vs 0.4920 ms): tools/rt_knobs.py, alternating in one process
-        uint32_t order = cfg.out_spread ? 1u : 0u;
-        if (const char *e = std::getenv("IGDSP_RT_ORDER")) order = (uint32_t)std::atoi(e);   // experiments
         const uint32_t grid = blocks_for((uint64_t)n_groups * n_seg, waves, (uint32_t)cfg.compute_units);
         if (kernel_variant == 4) {
             if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_G191>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);

@@ -133,6 +133,33 @@ def test_other_frame_sizes_image_kernel(ctx, orc, n, ragged):
     assert agg["peak_slot"].tolist() == eagg["peak_slot"].tolist()
 
 
+@pytest.mark.parametrize("n", [160, 164])
+def test_roundtrip_group_order_of_spread_outputs(ctx, orc, n):
+    """When the re-encoded output sits half in one, half in another memory class (igdsp_io_alloc), the fused round-trip kernels
+    give the waves of a block CONSECUTIVE channel groups in their first round and groups a grid apart in any remainder round.
+    That order is forced here (IGDSP_RT_ORDER=1, read at launch) on a shape with a remainder round — 4 000 groups for 3 072
+    waves — and on one with frame segments; codes, records and hold windows against the oracle."""
+    import os
+    torch = gu.torch_cuda()
+    for C_, F_ in ((64 * 4000, 2), (64 * 37, 40)):
+        payload = orc.gen_uniform(F_ * C_ * n, seed=C_ + n).reshape(F_, C_, n)
+        codec = np.where(np.arange(C_) % 3 == 0, 8, 0).astype(np.uint8)
+        hold0 = gu.new_hold(C_)
+        eout, est, ehold = orc.roundtrip_peakhold(payload, codec, hold0.copy().view(orc.CHAN_HOLD))
+        d_out, d_st, d_hold = gu.dev_zeros(F_ * C_ * n, 0xEE), gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.to_dev(hold0)
+        os.environ["IGDSP_RT_ORDER"] = "1"
+        try:
+            ctx.roundtrip_peakhold(gu.to_dev(payload), gu.to_dev(codec), C_, F_, n, d_out, d_st, d_hold)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["IGDSP_RT_ORDER"]
+        assert np.array_equal(gu.to_host(d_out, np.uint8, (F_, C_, n)), eout)
+        gu.assert_stats_equal(gu.to_host(d_st, capi.FRAME_STATS, (F_, C_)), est, n=n)
+        ghold = gu.to_host(d_hold, capi.CHAN_HOLD)
+        for f in capi.CHAN_HOLD.names:
+            assert np.array_equal(ghold[f], ehold[f]), f
+
+
 @pytest.mark.parametrize("n", [164, 24, 240, 128])
 def test_strided_peak_is_exact_for_every_code(ctx, orc, n):
     """The record-only k_meter_strided kernels look up (|x| / 4)^2 alone and recover the peak as the integer root of the largest
