@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the N>1 path's ONLY exchange step: the packed aggregate vector
+"""world_size-2 and -8 gloo tests of the N>1 path's ONLY exchange step: the packed aggregate vector
 (SURVEY 8e).  One sum all-reduce must yield the node-wide sums AND the max peak, because rank g
 writes its local peak only into peak_slot[g].  The per-rank aggregates come from the oracle here
 (no GPU in this container); the -m gpu suite checks that the kernels fill the same vector."""
@@ -40,15 +40,19 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_aggregate_allreduce_world2():
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8])                # 8 = the driver's scaling run: every peak slot, odd channel splits
+def test_aggregate_allreduce(world):
     from oracle import oracle as orc
 
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in ps]
-    res = sorted(q.get(timeout=120) for _ in range(world))
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda r: r[0])
     [p.join(60) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
     # single-process truth over the whole array
@@ -61,7 +65,7 @@ def test_aggregate_allreduce_world2():
         assert node["frames"] == C_total * F_ and node["byte_mean_sum"] == int(agg["byte_mean_sum"])
         assert node["peak"] == int(st["peak"].max()) == max(r[2] for r in res)
         assert abs(node["rms"] - np.sqrt(int(agg["sumsq"]) / (C_total * F_ * n))) < 1e-9
-    assert res[0][1] == res[1][1]                      # every rank holds the same node-wide view
+    assert all(r[1] == res[0][1] for r in res)          # every rank holds the same node-wide view
 
 
 def test_channel_ranges_partition():
