@@ -403,6 +403,9 @@ constexpr int kStripEntries = kSuperFrames * kPiecesPerFrame;  // 640 x 8 B = 5 
 #endif
 __device__ __forceinline__ uint32_t spread_batch(uint32_t b, uint32_t nb)
 {
+#ifdef IGDSP_NO_SPREAD          // A/B builds only: ascending order everywhere
+    return b;
+#endif
     const uint32_t half = (nb + 1u) >> 1;
     return b >= nb ? b : ((b & 1u) ? half + (b >> 1) : (b >> 1));
 }

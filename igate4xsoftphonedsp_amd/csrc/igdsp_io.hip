@@ -473,7 +473,7 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
             };
             // inputs: the chunks of source A themselves plus chunks that write slowly against it (the same class)
             if (in_chunks > kSrcChunks) walk(0, in_chunks - kSrcChunks, slow_A, poolA);
-            const bool want_spread = bulk_chunks >= 8;
+            const bool want_spread = bulk_chunks >= 8 && std::getenv("IGDSP_IO_NO_SPREAD") == nullptr;   // (experiments: two classes only)
             // (with a bulk output the pool also has to yield source B and enough members of either class to re-seed it from)
             walk(0, want_spread ? std::max<size_t>(rec_chunks + bulk_chunks + kSrcChunks, 4 * kSrcChunks) : rec_chunks + bulk_chunks, fast_A, poolB);
 
