@@ -122,9 +122,6 @@ __global__ __launch_bounds__(256) void k_meter_wave_per_frame(
 // units of 8 samples: unit u+1's eight ds_read_b64 are in flight while unit u is folded, so a wave
 // hides most LDS latency by itself (at most 16 LDS reads outstanding = the lgkmcnt limit).
 // ----------------------------------------------------------------------------
-#ifndef IGDSP_STORE_XPOSE
-#define IGDSP_STORE_XPOSE 1
-#endif
 template <bool STORE_PCM>
 __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half, uint4 (&d)[kLoadsPerChunk],
                                              const uint32_t am, const uint32_t (&fr)[kLoadsPerChunk], const uint32_t (&pm)[kLoadsPerChunk],
@@ -170,12 +167,9 @@ __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half
         if (k == 1) {                           // piece j complete
             strip_half[j * 64 + lane] = make_uint2(sum, peak | (bsum << 16) | probe_fail(d[j], pm[j]));
             if (STORE_PCM) {
-                // Each lane holds 32 contiguous PCM bytes (A = o[0..3], B = o[4..7]); four neighbouring lanes hold
-                // 128.  A quad-local DPP shuffle regroups them so that one store instruction writes 64 contiguous
-                // bytes per quad (lane i of the quad stores 16-byte chunk i, the second store chunk 4 + i)
-                // instead of 16-byte pieces at 32-byte stride.  Plain (cached) stores: L2 merges the two halves
-                // of a line; the nontemporal form measured 18 % slower on this pattern.
-#if IGDSP_STORE_XPOSE
+                // Each lane holds 32 contiguous PCM bytes (A = o[0..3], B = o[4..7]): stored from the lanes' own registers they
+                // would leave as 16-byte pieces at 32-byte stride.  (History, DESIGN 3.4b: a quad-local DPP regroup wrote 64
+                // contiguous bytes per quad; nontemporal stores measured 18 % slower on this pattern.)
                 // transposition through a per-wave 2 KiB LDS scratch: lane l parks its 32 bytes at l * 32, then reads back
                 // bytes [16 l, 16 l + 16) of each KiB, so both store instructions write 1 KiB contiguous (whole lines)
                 // (16-byte unit u lives at u ^ ((u >> 3) & 1): lanes l and l + 4 of a ds_write_b128 pass would otherwise meet in the
@@ -189,22 +183,6 @@ __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half
                 uint4 *op = pcm_half + ((uint32_t)j * 128u + lane);
                 op[0] = v0;
                 op[64] = v1;
-#else
-                const bool odd = (lane & 1u) != 0u;
-                uint32_t s1[4], s2[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t ta = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o[i], 0x50, 0xF, 0xF, false);       // quad_perm [0,0,1,1]
-                    const uint32_t tb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o[4 + i], 0x50, 0xF, 0xF, false);
-                    const uint32_t ua = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o[i], 0xFA, 0xF, 0xF, false);       // quad_perm [2,2,3,3]
-                    const uint32_t ub = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o[4 + i], 0xFA, 0xF, 0xF, false);
-                    s1[i] = odd ? tb : ta;
-                    s2[i] = odd ? ub : ua;
-                }
-                uint4 *op = pcm_half + ((uint32_t)j * 128u + (lane >> 2) * 8u + (lane & 3u));
-                op[0] = make_uint4(s1[0], s1[1], s1[2], s1[3]);
-                op[4] = make_uint4(s2[0], s2[1], s2[2], s2[3]);
-#endif
             }
             d[j] = ld_stream(refill + j * 64);
             sum = 0; peak = 0; bsum = 0;
