@@ -16,12 +16,17 @@ issued on a side stream behind the kernel's event.
 Buffers come from the C ABI: the whole input / output set of the step from ONE igdsp_io_alloc call, which places inputs,
 records and bulk outputs in different classes of device memory (on MI355X a launch that reads one class and writes another
 is ~13 % faster) — this file carries no placement logic of its own.  The same step is ALSO timed on plain
-consecutive igdsp_dev_alloc buffers without any clock pre-warm: `roofline.frac_unassisted` beside `roofline.frac`.
-Before the W warm-up steps of the headline measurement the launch is repeated for ~60 ms so the clocks settle (a gateway
-that runs continuously is always in that state); none of this is inside a step.
+consecutive igdsp_dev_alloc buffers — what a host gets that follows include/igdsp.h literally — twice: straight after the
+allocation with W warm-up launches only (`roofline.frac_plain_cold`) and after the same ~60 ms clock pre-warm the headline
+gets (`roofline.frac_plain_warm`: placement is then the ONLY difference to `roofline.frac`).  `placement_setup_ms` (top
+level) is what the placed set cost at start-up.  Before the W warm-up steps of the headline measurement the launch is
+repeated for ~60 ms so the clocks settle (a gateway that runs continuously is always in that state); none of this is inside a step.
 
 Rank 0 prints ONE JSON line; `roofline` is measured live with one pair of HIP events on the launch
-stream around the K timed launches (average launch duration = elapsed / K), `cpu_baseline` is the CPU oracle timed on this box's host cores (N = 1 only).
+stream around the K timed launches (average launch duration = elapsed / K); a second pass of >= 20 launches, each between
+its own pair of events, gives `roofline.median_ms / min_ms / max_ms` (BASELINE.md section 3 asks for the median; a pair
+per launch adds event handling to every launch, so that pass is not the headline).  `cpu_baseline` is the CPU oracle timed
+on this box's host cores (N = 1 only), one frame per call through its single-frame entry.
 """
 from __future__ import annotations
 
@@ -75,7 +80,7 @@ def parse():
                          "GPU needs ~20 ms of load to reach its steady clocks (first 30 launches measure ~6 %% slow)")
     ap.add_argument("--wav-offset", type=int, default=84, help="wav mode: byte offset of file 0 inside its buffer (84: data bytes line-aligned; 0: headers line-aligned)")
     ap.add_argument("--placement", choices=["both", "abi", "plain"], default="both",
-                    help="both: headline on igdsp_io_alloc buffers + the unassisted figure on plain igdsp_dev_alloc buffers; "
+                    help="both: headline on igdsp_io_alloc buffers + the plain-allocation figures (cold and pre-warmed) on igdsp_dev_alloc buffers; "
                          "abi / plain: only that one (plain = the headline itself runs on plain buffers)")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1 only: bring up a 1-rank nccl (= RCCL) group and run the N > 1 step sequence (kernel -> event -> "
@@ -96,18 +101,21 @@ def cpu_baseline(seconds: float):
     codec = np.zeros((C_,), np.uint8)
     samples = payload.size
     cores = len(os.sched_getaffinity(0))
-    t1 = orc.time_decode_meter(payload, codec, 1, 1)
-    reps1 = max(1, int(0.25 * seconds / max(t1, 1e-6)))
-    t1 = orc.time_decode_meter(payload, codec, 1, reps1) / reps1
-    tn = orc.time_decode_meter(payload, codec, cores, 1)
-    repsn = max(1, int(0.6 * seconds / max(tn, 1e-6)))
-    tn = orc.time_decode_meter(payload, codec, cores, repsn) / repsn
+    t1 = orc.time_single_frame(payload, codec, 1, 1)
+    reps1 = max(1, int(0.2 * seconds / max(t1, 1e-6)))
+    t1 = orc.time_single_frame(payload, codec, 1, reps1) / reps1
+    tn = orc.time_single_frame(payload, codec, cores, 1)
+    repsn = max(1, int(0.4 * seconds / max(tn, 1e-6)))
+    tn = orc.time_single_frame(payload, codec, cores, repsn) / repsn
+    tl = orc.time_decode_meter(payload, codec, cores, max(1, repsn // 2)) / max(1, repsn // 2)     # the same arithmetic as one batch loop
     tb = orc.time_byte_mean(payload, cores, max(1, repsn // 2)) / max(1, repsn // 2)
     return {
         "value": round(samples / tn / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
-        "sample": f"oracle B1 (scalar table decode + u64 sum x^2 + peak + sqrt, -O2) on the first {C_} ch x {F_} frames "
+        "sample": f"oracle B1 (scalar table decode + u64 sum x^2 + peak + sqrt, -O2), ONE FRAME PER CALL through the oracle's "
+                  f"single-frame entry (call id -> slot, as igdsp_on_rtp_frame takes it), on the first {C_} ch x {F_} frames "
                   f"({samples / 1e6:.0f} MB: cache-resident on the host) of the same D-uniform stream, x{repsn} passes, {cores} pthreads",
         "single_thread_value": round(samples / t1 / 1e6, 2),
+        "batch_loop_value": round(samples / tl / 1e6, 2),
         "reference_loop_byte_mean_value": round(samples / tb / 1e6, 2),
         "cpu_model": _cpu_model(), "compiler_flags": "gcc -O2 -funsigned-char (oracle/Makefile; -O2 as the reference's .pro:88)",
     }
@@ -181,7 +189,7 @@ def main():
     #   "plain": igdsp_dev_alloc one after the other, inputs first — what a host writes when it follows the header literally;
     #   "abi"  : ONE igdsp_io_alloc call for the whole set — the library places inputs / records / bulk outputs in different
     #            classes of device memory (no search or arena lives in this file any more).
-    # The driver line's `value` / `roofline.frac` are measured on the "abi" set, `roofline.frac_unassisted` on the "plain" one.
+    # The driver line's `value` / `roofline.frac` are measured on the "abi" set, `roofline.frac_plain_warm` / `_cold` on the "plain" one.
     U8, I16, I64 = torch.uint8, torch.int16, torch.int64
     MODE = args.mode
     spec = []                                    # (name, shape, dtype, role)
@@ -319,14 +327,26 @@ def main():
 
     scratch_agg = torch.zeros((capi.AGG_WORDS,), dtype=torch.int64, device="cuda")
 
-    # ---- the unassisted figure: plain consecutive allocations, no clock pre-warm, W warm-up launches, K timed ones
-    unassisted_ms = None
+    def prewarm(B):
+        """clock pre-warm (not steps: no aggregate ring, no collective): the GPU needs ~20 ms of load to reach its steady clocks"""
+        spent = 0.0
+        while spent < args.prewarm_ms:
+            spent += 20 * gpu_ms(lambda: launch(scratch_agg, B), 20)
+
+    # ---- the plain figures: consecutive igdsp_dev_alloc buffers (a host that follows the header literally).  Cold = W warm-up
+    # launches, K timed ones, nothing else; warm = the same K launches after the headline's own clock pre-warm, so that the
+    # ONLY difference between frac_plain_warm and frac is where the buffers sit.
+    plain_cold_ms = plain_warm_ms = None
     if args.placement in ("both", "plain"):
         P = BufSet("plain")
         for _ in range(args.warmup):
             launch(scratch_agg, P)
-        unassisted_ms = gpu_ms(lambda: launch(scratch_agg, P), args.steps)
+        plain_cold_ms = gpu_ms(lambda: launch(scratch_agg, P), args.steps)
         if args.placement == "both":
+            prewarm(P)
+            for _ in range(args.warmup):
+                launch(scratch_agg, P)
+            plain_warm_ms = gpu_ms(lambda: launch(scratch_agg, P), args.steps)
             P.close()
             del P
     if args.placement == "plain":
@@ -348,10 +368,7 @@ def main():
         with torch.cuda.stream(comm_s):
             dist.all_reduce(prime, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
-    # clock pre-warm (not steps: no aggregate ring, no collective): the GPU needs ~20 ms of load to reach its steady clocks
-    spent = 0.0
-    while spent < args.prewarm_ms:
-        spent += 20 * gpu_ms(lambda: launch(scratch_agg, OUT), 20)
+    prewarm(OUT)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -376,6 +393,22 @@ def main():
     # average launch duration: the K launches run back to back on `hs`, bracketed by ONE pair of HIP events on that
     # stream (bracketing every launch with its own pair adds ~10 us of event handling to each 0.25 ms launch)
     kern_avg_ms = region.elapsed_ms() / args.steps
+    if args.placement == "plain":
+        plain_warm_ms = kern_avg_ms                   # the headline itself ran on plain buffers, pre-warmed
+    # "median of >= 20 launches after 3 warm-ups" — a pass of its own, every launch between its own
+    # pair of events (no aggregate ring, no collective: the kernel alone)
+    n_med = max(20, args.steps)
+    for _ in range(3):
+        launch(scratch_agg, OUT)
+    pairs = [ctx.timer() for _ in range(n_med)]
+    for t in pairs:
+        t.start(hs)
+        launch(scratch_agg, OUT)
+        t.stop(hs)
+    per_launch = sorted(t.elapsed_ms() for t in pairs)
+    for t in pairs:
+        t.close()
+    median_ms = per_launch[n_med // 2] if n_med % 2 else 0.5 * (per_launch[n_med // 2 - 1] + per_launch[n_med // 2])
     coll_info = None
     if args.force_collective and world == 1:
         # the same K steps again WITHOUT the event + side-stream all-reduce: what the N > 1 sequence costs a launch
@@ -401,6 +434,9 @@ def main():
     achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9
     kernel_name = "k_encode_lut16" if args.mode == "encode" else "k_wav_expand16" if args.mode == "wav" else "k_meter_rtp64" if args.mode in ("rtp", "packets") else "k_depayload64" if args.mode == "depayload" else ("k_roundtrip_chunk64" if args.variant == 4 else "k_roundtrip_lut64" if n == N_SAMPLES else "k_roundtrip_strided") if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64" if n == N_SAMPLES else "k_meter_strided" if ((n >> 4) in (1, 4, 5, 6, 8, 10, 12, 15) and (n >> 2) & 3 != 3 and n not in (244, 248)) else "k_meter_image")
 
+    def frac_of(ms):
+        return None if ms is None else round(samples_per_step_rank * bps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+
     out = {
         "metric": "Msamples/s G.711 decode+RMS, 65536ch@8kHz; %HBM roofline at 1/2/4/8 GPU",
         "value": round(value, 1),
@@ -425,10 +461,13 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "frac_unassisted": None if unassisted_ms is None else round(samples_per_step_rank * bps / (unassisted_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "kernel_avg_ms_unassisted": None if unassisted_ms is None else round(unassisted_ms, 4),
+            "frac_plain_warm": frac_of(plain_warm_ms), "frac_plain_cold": frac_of(plain_cold_ms),
+            "kernel_avg_ms_plain_warm": None if plain_warm_ms is None else round(plain_warm_ms, 4),
+            "kernel_avg_ms_plain_cold": None if plain_cold_ms is None else round(plain_cold_ms, 4),
             "traffic": None,
             "kernel": kernel_name, "kernel_avg_ms": round(kern_avg_ms, 4),
+            "median_ms": round(median_ms, 4), "min_ms": round(per_launch[0], 4), "max_ms": round(per_launch[-1], 4),
+            "median_launches": n_med, "frac_median": frac_of(median_ms),
             "algorithmic_bytes_per_sample": round(bps, 5),
             "algorithmic_bytes_per_launch": int(samples_per_step_rank * bps),
         },
@@ -480,6 +519,7 @@ def main():
             pass
 
     out["config"]["placement"] = {"headline_buffers": OUT.how, "io_alloc_report": OUT.report}
+    out["placement_setup_ms"] = None if not OUT.report else OUT.report.get("setup_ms")     # start-up cost of the placed set (not in any step)
     if coll_info:
         out["collective"] = coll_info
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

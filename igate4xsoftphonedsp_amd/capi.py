@@ -248,10 +248,10 @@ class Context:
         self._ck(self.L.igdsp_decode_meter(self.h, _ptr(payload), _ptr(codec), _ptr(length), C_, F_, n, _ptr(stats),
                                            _ptr(pcm), _ptr(agg), rank, stream), "igdsp_decode_meter")
 
-    def encode(self, pcm, codec, C_, F_, n, out, variant=ENC_SUN16, stream=None):
+    def encode(self, pcm, codec, C_, F_, n, out, variant=ENC_G191, stream=None):
         self._ck(self.L.igdsp_encode(self.h, _ptr(pcm), _ptr(codec), C_, F_, n, _ptr(out), variant, stream), "igdsp_encode")
 
-    def roundtrip_peakhold(self, payload, codec, C_, F_, n, out, stats, hold, gate=None, variant=ENC_SUN16, stream=None):
+    def roundtrip_peakhold(self, payload, codec, C_, F_, n, out, stats, hold, gate=None, variant=ENC_G191, stream=None):
         self._ck(self.L.igdsp_roundtrip_peakhold(self.h, _ptr(payload), _ptr(codec), C_, F_, n, _ptr(out), _ptr(stats),
                                                  _ptr(hold), _ptr(gate), variant, stream), "igdsp_roundtrip_peakhold")
 

@@ -104,6 +104,10 @@ int igdsp_create(igdsp_ctx **out, int device, uint32_t max_channels)
         igdsp_destroy(ctx);
         return IGDSP_ENOMEM;
     }
+    if (init_device_attributes() != hipSuccess) {      // this device's kernel attributes (hipSetDevice above)
+        igdsp_destroy(ctx);
+        return IGDSP_EDEVICE;
+    }
     std::memset(ctx->h_stats, 0, max_channels * sizeof(igdsp_frame_stats));
     if (launch_hold_reset(ctx->d_hold, max_channels, nullptr, ctx->stream) != hipSuccess ||
         hipMemcpyAsync(ctx->h_hold, ctx->d_hold, max_channels * sizeof(igdsp_chan_hold), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -259,11 +263,11 @@ int igdsp_flush(igdsp_ctx *ctx, uint32_t *n_frames_out)
     // records: group A first, then group B.  Each staged frame is its own "channel" of a one-frame batch (its codec = its PT).
     igdsp_frame_stats *stA = ctx->d_stats, *stB = ctx->d_stats + nA;
     if (nA) {   // whole 160-byte frames, dense: the chunk kernel takes every 64, the general kernel the < 64 left over
-        HIP_TRY(ctx, launch_decode_meter(cfg_of(ctx), 0, d + L.payA, d + L.ptA, nullptr, nA, 1, IGDSP_SAMPLES_PER_FRAME, stA, nullptr, nullptr, 0, s));
+        HIP_TRY(ctx, launch_decode_meter(cfg_of(ctx, s), 0, d + L.payA, d + L.ptA, nullptr, nA, 1, IGDSP_SAMPLES_PER_FRAME, stA, nullptr, nullptr, 0, s));
         HIP_TRY(ctx, launch_hold_fold_runs(stA, nullptr, IGDSP_SAMPLES_PER_FRAME, reinterpret_cast<const uint32_t *>(d + L.runA), nrA, ctx->d_hold, s));
     }
     if (nB) {   // every other length: 256-byte slots with a length per frame
-        HIP_TRY(ctx, launch_decode_meter(cfg_of(ctx), 1, d + L.payB, d + L.ptB, reinterpret_cast<const uint16_t *>(d + L.lenB), nB, 1, kSlot, stB, nullptr, nullptr, 0, s));
+        HIP_TRY(ctx, launch_decode_meter(cfg_of(ctx, s), 1, d + L.payB, d + L.ptB, reinterpret_cast<const uint16_t *>(d + L.lenB), nB, 1, kSlot, stB, nullptr, nullptr, 0, s));
         HIP_TRY(ctx, launch_hold_fold_runs(stB, reinterpret_cast<const uint16_t *>(d + L.lenB), kSlot, reinterpret_cast<const uint32_t *>(d + L.runB), nrB, ctx->d_hold, s));
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fresh, ctx->d_stats, (size_t)staged * sizeof(igdsp_frame_stats), hipMemcpyDeviceToHost, s));
@@ -344,7 +348,7 @@ int igdsp_decode_meter(igdsp_ctx *ctx, const uint8_t *d_payload, const uint8_t *
     if (int rc = check_shape(C, F, n)) return rc;
     if (rank >= IGDSP_AGG_MAX_RANKS) return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_decode_meter(cfg_of(ctx), ctx->variant, d_payload, d_codec, d_len, C, F, n, d_stats, d_pcm, d_agg, rank, pick(ctx, stream)));
+    HIP_TRY(ctx, launch_decode_meter(cfg_of(ctx, pick(ctx, stream)), ctx->variant, d_payload, d_codec, d_len, C, F, n, d_stats, d_pcm, d_agg, rank, pick(ctx, stream)));
     return IGDSP_OK;
 }
 
@@ -357,7 +361,7 @@ int igdsp_encode(igdsp_ctx *ctx, const int16_t *d_pcm, const uint8_t *d_codec, u
     if (variant != IGDSP_ENC_SUN16 && variant != IGDSP_ENC_G191) return IGDSP_EINVAL;
     if (int rc = check_shape(C, F, n)) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_encode(cfg_of(ctx), d_pcm, d_codec, C, F, n, d_out, variant, pick(ctx, stream)));
+    HIP_TRY(ctx, launch_encode(cfg_of(ctx, pick(ctx, stream)), d_pcm, d_codec, C, F, n, d_out, variant, pick(ctx, stream)));
     return IGDSP_OK;
 }
 
@@ -374,7 +378,7 @@ int igdsp_roundtrip_peakhold(igdsp_ctx *ctx, const uint8_t *d_payload, const uin
     // every shape is served: whole groups of 64 channels of 160-byte frames by the fused channel-group-major kernel,
     // the remaining channels and every other geometry by the general wave-per-channel kernel (launch_roundtrip)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    igdsp::LaunchCfg cfg = cfg_of(ctx);
+    igdsp::LaunchCfg cfg = cfg_of(ctx, pick(ctx, stream));
     cfg.out_spread = ctx->is_spread(d_out);
     HIP_TRY(ctx, launch_roundtrip(cfg, ctx->variant, d_payload, d_codec, C, F, n, d_out, d_stats, d_hold, d_gate, variant, pick(ctx, stream)));
     return IGDSP_OK;
@@ -419,7 +423,7 @@ int igdsp_depayload(igdsp_ctx *ctx, const uint8_t *d_packets, const uint16_t *d_
     // slots hold at least a 20-byte header, are dword-granular (so header words and payload dwords are aligned)
     if (pkt_stride < 20u || (pkt_stride & 3u) || pkt_stride > 2048u || (reinterpret_cast<uintptr_t>(d_packets) & 3u)) return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_depayload(cfg_of(ctx), d_packets, d_sizes, d_radio, C, F, pkt_stride, n, d_payload_out, d_len_out, d_info_out, pick(ctx, stream)));
+    HIP_TRY(ctx, launch_depayload(cfg_of(ctx, pick(ctx, stream)), d_packets, d_sizes, d_radio, C, F, pkt_stride, n, d_payload_out, d_len_out, d_info_out, pick(ctx, stream)));
     return IGDSP_OK;
 }
 
@@ -436,7 +440,7 @@ int igdsp_decode_meter_rtp(igdsp_ctx *ctx, const uint8_t *d_slots, const uint8_t
         (reinterpret_cast<uintptr_t>(d_info) & 7u))
         return fail(ctx, IGDSP_EINVAL, "decode_meter_rtp needs C*F % 64 == 0 and 16-byte aligned slots / stats");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_decode_meter_rtp(cfg_of(ctx), d_slots, nullptr, d_codec, C, F, 0, 20, d_stats, d_info, d_agg, rank, pick(ctx, stream)));
+    HIP_TRY(ctx, launch_decode_meter_rtp(cfg_of(ctx, pick(ctx, stream)), d_slots, nullptr, d_codec, C, F, 0, 20, d_stats, d_info, d_agg, rank, pick(ctx, stream)));
     return IGDSP_OK;
 }
 
@@ -456,7 +460,7 @@ int igdsp_decode_meter_packets(igdsp_ctx *ctx, const uint8_t *d_packets, const u
         (reinterpret_cast<uintptr_t>(d_info) & 7u) || (reinterpret_cast<uintptr_t>(d_sizes) & 1u))
         return fail(ctx, IGDSP_EINVAL, "decode_meter_packets needs C*F % 64 == 0, dword-aligned packets, 16-byte aligned stats");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_decode_meter_rtp(cfg_of(ctx), d_packets, d_sizes, d_codec, C, F, pkt_stride, hdr_bytes, d_stats, d_info, d_agg, rank, pick(ctx, stream)));
+    HIP_TRY(ctx, launch_decode_meter_rtp(cfg_of(ctx, pick(ctx, stream)), d_packets, d_sizes, d_codec, C, F, pkt_stride, hdr_bytes, d_stats, d_info, d_agg, rank, pick(ctx, stream)));
     return IGDSP_OK;
 }
 
@@ -474,7 +478,7 @@ int igdsp_decode_meter_packets_mixed(igdsp_ctx *ctx, const uint8_t *d_packets, c
         (reinterpret_cast<uintptr_t>(d_info) & 7u) || (reinterpret_cast<uintptr_t>(d_sizes) & 1u))
         return fail(ctx, IGDSP_EINVAL, "decode_meter_packets_mixed needs C*F % 64 == 0, dword-aligned packets, 16-byte aligned stats");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_decode_meter_rtp(cfg_of(ctx), d_packets, d_sizes, d_codec, C, F, pkt_stride, 12, d_stats, d_info, d_agg, rank, pick(ctx, stream), d_radio));
+    HIP_TRY(ctx, launch_decode_meter_rtp(cfg_of(ctx, pick(ctx, stream)), d_packets, d_sizes, d_codec, C, F, pkt_stride, 12, d_stats, d_info, d_agg, rank, pick(ctx, stream), d_radio));
     return IGDSP_OK;
 }
 
@@ -489,7 +493,7 @@ int igdsp_wav_expand(igdsp_ctx *ctx, const uint8_t *d_payload, uint32_t C, uint3
     const uint64_t file_bytes = 44ull + 2ull * F * n;
     if (file_stride < file_bytes || 2ull * F * n > 0xFFFFFFFFull - 36ull) return IGDSP_EINVAL;   // the header's sizes are 32-bit
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_wav_expand(cfg_of(ctx), d_payload, C, F, n, rate, d_files, file_stride, pick(ctx, stream)));
+    HIP_TRY(ctx, launch_wav_expand(cfg_of(ctx, pick(ctx, stream)), d_payload, C, F, n, rate, d_files, file_stride, pick(ctx, stream)));
     return IGDSP_OK;
 }
 
@@ -501,7 +505,7 @@ int igdsp_g726_reorder(igdsp_ctx *ctx, const uint8_t *d_in, uint8_t *d_out, uint
     const uint64_t group = (mode == 2) ? 3 : (mode == 4 ? 5 : 1);
     if (n_bytes % group) return IGDSP_EINVAL;               // the reference over-reads on partial groups
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_g726(cfg_of(ctx), d_in, d_out, n_bytes, mode, pick(ctx, stream)));
+    HIP_TRY(ctx, launch_g726(cfg_of(ctx, pick(ctx, stream)), d_in, d_out, n_bytes, mode, pick(ctx, stream)));
     return IGDSP_OK;
 }
 
@@ -517,7 +521,7 @@ int igdsp_stream_read(igdsp_ctx *ctx, const void *d_src, size_t bytes, uint64_t 
 {
     if (!ctx || !d_src || !d_sink || (reinterpret_cast<uintptr_t>(d_src) & 15u)) return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_stream_read(cfg_of(ctx), d_src, bytes, d_sink, pick(ctx, stream)));
+    HIP_TRY(ctx, launch_stream_read(cfg_of(ctx, pick(ctx, stream)), d_src, bytes, d_sink, pick(ctx, stream)));
     return IGDSP_OK;
 }
 
@@ -536,9 +540,9 @@ int igdsp_probe_placement(igdsp_ctx *ctx, const void *d_in, size_t bytes, void *
     }
     hipError_t e = hipEventCreate(&a);
     if (e == hipSuccess) e = hipEventCreate(&b);
-    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx), d_in, bytes, d_out, s);
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx, s), d_in, bytes, d_out, s);
     if (e == hipSuccess) e = hipEventRecord(a, s);
-    for (uint32_t i = 0; i < reps && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx), d_in, bytes, d_out, s);
+    for (uint32_t i = 0; i < reps && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx, s), d_in, bytes, d_out, s);
     if (e == hipSuccess) e = hipEventRecord(b, s);
     if (e == hipSuccess) e = hipEventSynchronize(b);
     float ms = 0.f;
@@ -571,7 +575,7 @@ int igdsp_internal_encode_table(igdsp_ctx *ctx, const int16_t *d_pcm, const uint
 {
     if (!ctx || !d_pcm || !d_codec || !d_out || (variant != IGDSP_ENC_SUN16 && variant != IGDSP_ENC_G191)) return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_encode_table(cfg_of(ctx), d_pcm, d_codec, C, F, n, d_out, variant, pick(ctx, stream)));
+    HIP_TRY(ctx, launch_encode_table(cfg_of(ctx, pick(ctx, stream)), d_pcm, d_codec, C, F, n, d_out, variant, pick(ctx, stream)));
     return IGDSP_OK;
 }
 
@@ -581,7 +585,7 @@ int igdsp_internal_stream_rw(igdsp_ctx *ctx, const void *d_src, size_t bytes, vo
 {
     if (!ctx || !d_src || !d_dst || (reinterpret_cast<uintptr_t>(d_src) & 15u) || (reinterpret_cast<uintptr_t>(d_dst) & 15u)) return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_stream_rw(cfg_of(ctx), d_src, bytes, d_dst, pick(ctx, stream)));
+    HIP_TRY(ctx, launch_stream_rw(cfg_of(ctx, pick(ctx, stream)), d_src, bytes, d_dst, pick(ctx, stream)));
     return IGDSP_OK;
 }
 
@@ -591,7 +595,7 @@ int igdsp_internal_stream_pieces(igdsp_ctx *ctx, const void *d_src, uint32_t n_i
 {
     if (!ctx || !d_src || !d_dst || (stride & 3u) || stride < 16u * (uint32_t)(rows - (mode == 0 ? 2 : 1))) return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_stream_pieces(cfg_of(ctx), d_src, n_items, stride, hdr, mode, rows, d_dst, d_dst2, pick(ctx, stream)));
+    HIP_TRY(ctx, launch_stream_pieces(cfg_of(ctx, pick(ctx, stream)), d_src, n_items, stride, hdr, mode, rows, d_dst, d_dst2, pick(ctx, stream)));
     return IGDSP_OK;
 }
 
@@ -602,7 +606,7 @@ int igdsp_internal_stream_mix(igdsp_ctx *ctx, const void *d_src, void *d_dst, ui
     // the source may be only dword aligned: that is what the calibration of misaligned 16-byte loads needs
     if (!ctx || !d_src || !d_dst || (reinterpret_cast<uintptr_t>(d_src) & 3u) || (reinterpret_cast<uintptr_t>(d_dst) & 15u)) return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_stream_mix(cfg_of(ctx), d_src, d_dst, n_items, r, w, waves, pick(ctx, stream)));
+    HIP_TRY(ctx, launch_stream_mix(cfg_of(ctx, pick(ctx, stream)), d_src, d_dst, n_items, r, w, waves, pick(ctx, stream)));
     return IGDSP_OK;
 }
 
@@ -612,7 +616,7 @@ int igdsp_internal_stream_mix2(igdsp_ctx *ctx, const void *d_src, void *d_dst, v
 {
     if (!ctx || !d_src || !d_dst || !d_dst2 || (reinterpret_cast<uintptr_t>(d_src2) & 15u) || ((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(d_dst) | reinterpret_cast<uintptr_t>(d_dst2)) & 15u)) return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_stream_mix(cfg_of(ctx), d_src, d_dst, n_items, r, w, waves, pick(ctx, stream), d_dst2, d_src2));
+    HIP_TRY(ctx, launch_stream_mix(cfg_of(ctx, pick(ctx, stream)), d_src, d_dst, n_items, r, w, waves, pick(ctx, stream), d_dst2, d_src2));
     return IGDSP_OK;
 }
 
@@ -623,7 +627,7 @@ int igdsp_internal_diag_chunk32(igdsp_ctx *ctx, const uint8_t *d_payload, const 
 {
     if (!ctx || !d_payload || !d_codec || !d_stats || !d_diag || C < 32) return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_diag_chunk32(cfg_of(ctx), d_payload, d_codec, C, F, d_stats, d_diag, pick(ctx, stream)));
+    HIP_TRY(ctx, launch_diag_chunk32(cfg_of(ctx, pick(ctx, stream)), d_payload, d_codec, C, F, d_stats, d_diag, pick(ctx, stream)));
     return IGDSP_OK;
 }
 
@@ -716,7 +720,10 @@ int igdsp_sync(igdsp_ctx *ctx, void *stream)
 {
     if (!ctx) return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t pos;
+    const uint32_t launches = queue_mark(ctx, pick(ctx, stream), &pos);
     HIP_TRY(ctx, hipStreamSynchronize(pick(ctx, stream)));
+    queue_release_if_idle(ctx, pick(ctx, stream), pos, launches);      // an idle stream gives its work-counter pair back
     return IGDSP_OK;
 }
 

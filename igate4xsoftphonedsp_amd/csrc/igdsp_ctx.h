@@ -66,15 +66,28 @@ struct igdsp_ctx {
     std::vector<uint32_t> newest;                       // scratch of igdsp_flush: record index of a channel's newest frame
     std::mutex flush_mu;
 
-    // device-wide work counters: a ring so that launches in flight on different streams never share one
-    uint32_t *d_queues = nullptr;                       // kQueueRing x 32 words (128 B apart)
-    std::atomic<uint32_t> queue_turn{0};
+    // device-wide work counters, ONE PAIR PER LAUNCH STREAM.  A persistent kernel draws its batches from the counter pair {next
+    // batch, blocks done} it is handed and its last block re-arms the pair, so two kernels may share a pair only if they can never
+    // be in flight together: launches on one stream serialise, launches on different streams do not.  (Round 2 handed launch k pair
+    // k % 64 with no completion check: with >= 64 launches pending on one stream a launch on another stream received a pair that
+    // was still in use — both kernels then drew batches from one counter: silently wrong records.)  A stream keeps its pair until
+    // igdsp_sync(ctx, stream) has seen it idle; when all pairs are taken a launch on a new stream runs the static per-block
+    // schedule (gqueue = nullptr: same results, ~2.5 % slower on the headline shape).
+    uint32_t *d_queues = nullptr;                       // kQueueRing x 32 words (pair i at word 32 i: 128 B apart)
+    hipStream_t queue_owner[64];                        // stream that owns pair i, or kFreeQueue (meaningful for i < queue_used)
+    uint32_t queue_launches[64];                        // launches handed pair i since it was taken (igdsp_sync's idle check)
+    uint32_t queue_used = 0;
+    uint32_t queue_hint = 0;                            // pair of the previous launch: the common case is one stream
+    std::atomic_flag queue_lk = ATOMIC_FLAG_INIT;
     bool global_queue = true;                           // device-wide batched work queue for k_meter_chunk64 (IGDSP_GLOBAL_QUEUE=0:
                                                         // static per-block batches).  Removes the inter-CU tail: -2.5 % on the
                                                         // headline launch once the outputs sit in another memory region than the
                                                         // payload (tools/kernel_ab.py); neutral when they share a region.
 };
-namespace { constexpr uint32_t kQueueRing = 64; }
+namespace {
+constexpr uint32_t kQueueRing = 64;
+const hipStream_t kFreeQueue = reinterpret_cast<hipStream_t>(~(uintptr_t)0);   // not a stream handle (NULL is one: the legacy default stream)
+}
 
 static inline int fail(igdsp_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
 {
@@ -96,10 +109,53 @@ static inline int fail(igdsp_ctx *ctx, int code, const char *what, hipError_t e 
 // NULL means what it means everywhere in HIP: the legacy default (null) stream, so a caller that
 // passes nothing stays ordered with its own default-stream work (e.g. torch tensors it just filled).
 static inline hipStream_t pick(igdsp_ctx *, void *stream) { return (hipStream_t)stream; }
-static inline igdsp::LaunchCfg cfg_of(igdsp_ctx *ctx)
+// The work-counter pair of `stream` (see igdsp_ctx::d_queues).  hipStreamPerThread names a different stream in every host thread,
+// so it cannot key a pair: those launches take the static schedule.
+static inline uint32_t *queue_of(igdsp_ctx *ctx, hipStream_t stream)
 {
+    if (!ctx->global_queue || !ctx->d_queues || stream == hipStreamPerThread) return nullptr;
+    while (ctx->queue_lk.test_and_set(std::memory_order_acquire)) {}
+    uint32_t i = ctx->queue_hint;
+    if (i >= ctx->queue_used || ctx->queue_owner[i] != stream) {
+        uint32_t free_i = kQueueRing;
+        for (i = 0; i < ctx->queue_used && ctx->queue_owner[i] != stream; ++i)
+            if (ctx->queue_owner[i] == kFreeQueue && free_i == kQueueRing) free_i = i;
+        if (i == ctx->queue_used) {                      // a stream without a pair: a released position first, else one more
+            if (free_i != kQueueRing) i = free_i;
+            else if (ctx->queue_used < kQueueRing) ctx->queue_used += 1;
+            else i = kQueueRing;                          // all taken: static schedule
+            if (i < kQueueRing) { ctx->queue_owner[i] = stream; ctx->queue_launches[i] = 0; }
+        }
+    }
     uint32_t *q = nullptr;
-    if (ctx->global_queue && ctx->d_queues) q = ctx->d_queues + 32u * (ctx->queue_turn.fetch_add(1, std::memory_order_relaxed) % kQueueRing);
-    return igdsp::LaunchCfg{ctx->cus, q};
+    if (i < kQueueRing) { ctx->queue_hint = i; ctx->queue_launches[i] += 1; q = ctx->d_queues + 32u * i; }
+    ctx->queue_lk.clear(std::memory_order_release);
+    return q;
+}
+// igdsp_sync brackets hipStreamSynchronize(stream) with these two: if no launch took the stream's pair in between, nothing of the
+// stream is in flight (its last kernel's last block has re-armed the pair) and the position is free for another stream.
+static inline uint32_t queue_mark(igdsp_ctx *ctx, hipStream_t stream, uint32_t *pos)
+{
+    uint32_t n = 0;
+    *pos = kQueueRing;
+    while (ctx->queue_lk.test_and_set(std::memory_order_acquire)) {}
+    for (uint32_t i = 0; i < ctx->queue_used; ++i)
+        if (ctx->queue_owner[i] == stream) { *pos = i; n = ctx->queue_launches[i]; break; }
+    ctx->queue_lk.clear(std::memory_order_release);
+    return n;
+}
+static inline void queue_release_if_idle(igdsp_ctx *ctx, hipStream_t stream, uint32_t pos, uint32_t launches_before)
+{
+    if (pos >= kQueueRing) return;
+    while (ctx->queue_lk.test_and_set(std::memory_order_acquire)) {}
+    if (pos < ctx->queue_used && ctx->queue_owner[pos] == stream && ctx->queue_launches[pos] == launches_before) {
+        ctx->queue_owner[pos] = kFreeQueue;
+        while (ctx->queue_used && ctx->queue_owner[ctx->queue_used - 1] == kFreeQueue) ctx->queue_used -= 1;
+    }
+    ctx->queue_lk.clear(std::memory_order_release);
+}
+static inline igdsp::LaunchCfg cfg_of(igdsp_ctx *ctx, hipStream_t stream)
+{
+    return igdsp::LaunchCfg{ctx->cus, queue_of(ctx, stream)};
 }
 

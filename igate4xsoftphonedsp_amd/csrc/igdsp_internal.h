@@ -25,6 +25,7 @@ struct LaunchCfg {
     bool out_spread = false;   // the launch's bulk output sits half in one, half in another memory class (igdsp_io_alloc)
 };
 
+hipError_t init_device_attributes();       // per-device kernel attributes; igdsp_create calls it with its device current
 hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant,
                                const uint8_t *payload, const uint8_t *codec, const uint16_t *len,
                                uint32_t C, uint32_t F, uint32_t n,

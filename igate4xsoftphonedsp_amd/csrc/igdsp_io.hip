@@ -94,9 +94,9 @@ struct Explorer {
     bool time_pair(const void *rd, void *dst, float *ms)
     {
         hipError_t e = hipSuccess;
-        for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx), rd, probe_n, dst, s);
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx, s), rd, probe_n, dst, s);
         if (e == hipSuccess) e = hipEventRecord(ea, s);
-        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx), rd, probe_n, dst, s);
+        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = launch_stream_rw(cfg_of(ctx, s), rd, probe_n, dst, s);
         if (e == hipSuccess) e = hipEventRecord(eb, s);
         if (e == hipSuccess) e = hipEventSynchronize(eb);
         float t = 0.f;

@@ -957,6 +957,21 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
               a_bm, a_peak, u_frames, u_sil, u_clip);
 }
 
+// Kernel attributes are per DEVICE: k_meter_image asks for more than 64 KiB of dynamic LDS (its frame images), which every device
+// that runs it has to be told once.  igdsp_create calls this with its device current (round 2 kept one flag per process, so in a
+// process with one context per GPU every device after the first would have had its image launches rejected).
+hipError_t init_device_attributes()
+{
+    const int lim = 160 * 1024 - 2048 - kLutEntries * 8;
+    const void *fns[] = {reinterpret_cast<const void *>(&k_meter_image<true, true>), reinterpret_cast<const void *>(&k_meter_image<false, true>),
+                         reinterpret_cast<const void *>(&k_meter_image<true, false>), reinterpret_cast<const void *>(&k_meter_image<false, false>)};
+    for (const void *f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t *payload, const uint8_t *codec,
                                const uint16_t *len, uint32_t C, uint32_t F, uint32_t n, igdsp_frame_stats *stats,
                                int16_t *pcm, igdsp_aggregate *agg, uint32_t rank, hipStream_t s)
@@ -1044,15 +1059,6 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
             const uint32_t items = (n_frames - done + (uint32_t)kSuperFrames - 1u) / (uint32_t)kSuperFrames;
             const uint32_t grid = blocks_for(items, waves, (uint32_t)cfg.compute_units);
             const size_t smem = (size_t)waves * img;              // dynamic part: the images (the LUT is static)
-            static bool attr_set = false;      // more than 64 KiB of dynamic LDS needs the attribute once per kernel
-            if (!attr_set) {
-                const int lim = 160 * 1024 - 2048 - (int)lut_bytes;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_meter_image<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_meter_image<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_meter_image<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_meter_image<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-                attr_set = true;
-            }
             const dim3 g3(grid), b3(waves * 64u);
             if (len) {
                 if (agg) hipLaunchKernelGGL((k_meter_image<true, true>), g3, b3, smem, s, payload, codec, len, C, done, n_frames, n, stats, agg, rank);

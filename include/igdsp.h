@@ -61,10 +61,19 @@ extern "C" {
  * Decode is unique (ITU-T G.711 tables).  Two historic encoders exist; they
  * agree on every value a decoder can produce and on ITU decision values, and
  * differ only in rounding of some negative inputs / clipping:
- *   SUN16 : 16-bit-domain Sun g711.c lineage (BIAS 0x84; A-law "-pcm-8" with
- *           the <0 clamp) — the lineage pjmedia's alaw_ulaw.c carries.
- *   G191  : 14/13-bit-domain ITU-T G.191 STL lineage (BIAS 0x21 after >>2;
- *           A-law "-pcm-1" after >>3) — bit-identical to CPython `audioop`.
+ *   SUN16 : 16-bit-domain Sun g711.c lineage (mu-law: BIAS 0x84 added to the
+ *           16-bit magnitude, clip 32635; A-law: "-pcm - 8" with the < 0 clamp).
+ *   G191  : 14/13-bit-domain ITU-T G.191 STL lineage (mu-law: pcm >> 2, BIAS 0x21,
+ *           clip 8159; A-law: pcm >> 3, "-pcm - 1") — bit-identical to CPython
+ *           `audioop`, which pins it exhaustively (tests/golden/g711_audioop.npz).
+ * WHICH of the two the reference's pjmedia build carries is UNVERIFIED: pjmedia is
+ * a third-party dependency of the reference, unpinned and absent from this tree
+ * (SURVEY.md 8c), and the reference holds no G.711 vector.  A maintainer with
+ * pjmedia's source picks the variant by reading pjmedia/src/pjmedia/alaw_ulaw.c
+ * against the two descriptions above (a ">> 2" / ">> 3" before the segment search
+ * = G191; a 16-bit BIAS 0x84 / "- 8" = SUN16).  Every binding and example of this
+ * repository defaults to G191, the one an independent implementation pins; the
+ * round trip of DECODED codes is identical in both (closed set, tested).
  */
 #define IGDSP_ENC_SUN16   0
 #define IGDSP_ENC_G191    1

@@ -448,15 +448,53 @@ void orc_ptt_released(orc_ptt_logger *l)                        /* Functions.cpp
 /* ------------------------------------------------------------------------- */
 typedef struct {
     const uint8_t *payload; const uint8_t *codec; uint32_t C, F, n, c0, c1; int reps;
-    orc_frame_stats *stats; uint8_t *bm; int mode;
+    orc_frame_stats *stats; uint8_t *bm; int mode; const int32_t *calls;
 } job_t;
 
 static int16_t g_tab[2][256];
 static int g_tab_ready;
 
+/* B1 "through the single-frame shim" (BASELINE.md section 2): the CPU counterpart of igdsp_on_rtp_frame — the inputs
+ * setIncomingRTP reads (callID, payload pointer, payload length, roip_ed137.cpp:6549-6552) plus the RTP PT
+ * (TransportAdapter.cpp:252), ONE frame per call: route the call id to its slot (the reference's if-chain,
+ * roip_ed137.cpp:6570-6585, as a table), table decode + sum x^2 + peak + byte mean + sqrt, leave the record in the slot.
+ * Reached through a volatile function pointer so that the per-frame call is a real call, as it is across a .so boundary. */
+typedef struct { const int32_t *slot_of_call; uint32_t n_calls; orc_frame_stats *slots; } orc_shim;
+
+static int orc_shim_on_rtp_frame(orc_shim *s, int32_t call_id, uint8_t pt, const uint8_t *payload, uint32_t n)
+{
+    if (pt != 0 && pt != 8) return 0;
+    if (call_id < 0 || (uint32_t)call_id >= s->n_calls) return -2;
+    const int32_t slot = s->slot_of_call[call_id];
+    if (slot < 0) return -2;
+    if (n == 0) return 0;
+    const int16_t *tab = g_tab[pt == 8];
+    uint64_t ss = 0; int peak = 0; int bs = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        int x = tab[payload[i]];
+        ss += (uint64_t)((int64_t)x * x);
+        int ax = x < 0 ? -x : x; if (ax > peak) peak = ax;
+        bs += payload[i];
+    }
+    orc_frame_stats *st = &s->slots[slot];
+    st->sumsq = ss; st->rms = (float)sqrt((double)ss / n); st->peak = (uint16_t)peak;
+    st->byte_mean = (uint8_t)(bs / (int)n);
+    st->flags = (uint8_t)((peak <= 8) | ((peak == (pt == 8 ? 32256 : 32124)) << 2));
+    return 0;
+}
+static int (*volatile g_frame_entry)(orc_shim *, int32_t, uint8_t, const uint8_t *, uint32_t) = orc_shim_on_rtp_frame;
+
 static void *worker(void *arg)
 {
     job_t *j = (job_t *)arg;
+    if (j->mode == 2) {          /* one call per frame; the record slots of this thread's channels are j->stats[c] */
+        orc_shim shim = { j->calls, j->C, j->stats };
+        for (int r = 0; r < j->reps; ++r)
+            for (uint32_t f = 0; f < j->F; ++f)
+                for (uint32_t c = j->c0; c < j->c1; ++c)
+                    (void)g_frame_entry(&shim, (int32_t)c, j->codec[c], j->payload + ((size_t)f * j->C + c) * j->n, j->n);
+        return NULL;
+    }
     for (int r = 0; r < j->reps; ++r)
         for (uint32_t f = 0; f < j->F; ++f)
             for (uint32_t c = j->c0; c < j->c1; ++c) {
@@ -504,13 +542,25 @@ static double run_threads(job_t proto, int threads)
 double orc_time_decode_meter(const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F, uint32_t n,
                              int threads, int reps, orc_frame_stats *stats)
 {
-    job_t j = { payload, codec, C, F, n, 0, 0, reps, stats, NULL, 0 };
+    job_t j = { payload, codec, C, F, n, 0, 0, reps, stats, NULL, 0, NULL };
     return run_threads(j, threads);
+}
+
+/* the same workload, ONE FRAME PER CALL through the single-frame shim (call id c -> slot c); slots = C records */
+double orc_time_single_frame(const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F, uint32_t n,
+                             int threads, int reps, orc_frame_stats *slots)
+{
+    int32_t *calls = (int32_t *)malloc(sizeof(int32_t) * (size_t)C);
+    for (uint32_t c = 0; c < C; ++c) calls[c] = (int32_t)c;
+    job_t j = { payload, codec, C, F, n, 0, 0, reps, slots, NULL, 2, calls };
+    const double t = run_threads(j, threads);
+    free(calls);
+    return t;
 }
 
 double orc_time_byte_mean(const uint8_t *payload, uint32_t C, uint32_t F, uint32_t n, int threads, int reps,
                           uint8_t *out)
 {
-    job_t j = { payload, NULL, C, F, n, 0, 0, reps, NULL, out, 1 };
+    job_t j = { payload, NULL, C, F, n, 0, 0, reps, NULL, out, 1, NULL };
     return run_threads(j, threads);
 }

@@ -14,8 +14,9 @@
  *    TransportAdapter.cpp:245).  The reference holds no tests or vectors for it
  *    => "parity unpinned" against pjmedia.  Decode is pinned against ITU-T G.711
  *    via SHA-256 KATs + CPython audioop fixtures (tests/golden/); encode variant
- *    G191 is pinned exhaustively against audioop; variant SUN16 (the lineage
- *    pjmedia carries) is pinned on the closed set enc(dec(c)) only.
+ *    G191 is pinned exhaustively against audioop; variant SUN16 is pinned on the
+ *    closed set enc(dec(c)) and on monotonicity / error-bound properties only.
+ *    Which of the two pjmedia carries is UNVERIFIED (pjmedia is absent here).
  *  - RMS / peak: not computed anywhere in the reference (audiometer.cpp reads
  *    ASCII levels from a FIFO); definition adopted in SURVEY.md 8(a5).
  */
@@ -105,6 +106,10 @@ void orc_ptt_released(orc_ptt_logger *l);
  * pthreads (static channel partition); returns seconds for all reps. */
 double orc_time_decode_meter(const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F, uint32_t n,
                              int threads, int reps, orc_frame_stats *stats);
+/* B1 of BASELINE.md section 2 as written: one frame per call through a single-frame entry shaped like igdsp_on_rtp_frame
+ * (call id -> slot routing, table decode, sum x^2, peak, byte mean, sqrt); slots = C records (each call's newest). */
+double orc_time_single_frame(const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F, uint32_t n,
+                             int threads, int reps, orc_frame_stats *slots);
 double orc_time_byte_mean(const uint8_t *payload, uint32_t C, uint32_t F, uint32_t n, int threads, int reps,
                           uint8_t *out);
 #ifdef __cplusplus

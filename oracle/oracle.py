@@ -102,6 +102,8 @@ def lib() -> C.CDLL:
         L.orc_wav_expand.restype = None; L.orc_wav_expand.argtypes = [vp, C.c_uint32, vp]
         L.orc_time_decode_meter.restype = C.c_double
         L.orc_time_decode_meter.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp]
+        L.orc_time_single_frame.restype = C.c_double
+        L.orc_time_single_frame.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp]
         L.orc_time_byte_mean.restype = C.c_double
         L.orc_time_byte_mean.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp]
         _lib = L
@@ -162,7 +164,7 @@ def decode_meter(payload, codec, length=None, want_pcm=False, want_agg=False, ra
     return out[0] if len(out) == 1 else tuple(out)
 
 
-def encode(pcm, codec, variant=ENC_SUN16):
+def encode(pcm, codec, variant=ENC_G191):
     pcm = np.ascontiguousarray(pcm, dtype="<i2")
     F_, C_, n = pcm.shape
     codec = np.ascontiguousarray(codec, dtype=np.uint8)
@@ -185,7 +187,7 @@ def hold_update(stats, n, hold, gate=None):
     return hold
 
 
-def roundtrip_peakhold(payload, codec, hold, gate=None, variant=ENC_SUN16):
+def roundtrip_peakhold(payload, codec, hold, gate=None, variant=ENC_G191):
     payload = np.ascontiguousarray(payload, dtype=np.uint8)
     F_, C_, n = payload.shape
     codec = np.ascontiguousarray(codec, dtype=np.uint8)
@@ -235,7 +237,7 @@ def gen_uniform(n_bytes: int, seed: int = SEED, first_byte: int = 0) -> np.ndarr
     return out
 
 
-def gen_speech(C_, F_, n, codec, seed: int = SEED, first_channel: int = 0, variant=ENC_SUN16) -> np.ndarray:
+def gen_speech(C_, F_, n, codec, seed: int = SEED, first_channel: int = 0, variant=ENC_G191) -> np.ndarray:
     codec = np.ascontiguousarray(codec, dtype=np.uint8)
     out = np.empty((F_, C_, n), dtype=np.uint8)
     lib().orc_gen_speech(_p(out), _p(codec), C_, F_, n, seed, first_channel, variant)
@@ -261,6 +263,15 @@ def time_decode_meter(payload, codec, threads: int, reps: int = 1) -> float:
     F_, C_, n = payload.shape
     stats = np.zeros((F_, C_), dtype=FRAME_STATS)
     return float(lib().orc_time_decode_meter(_p(payload), _p(np.ascontiguousarray(codec, np.uint8)), C_, F_, n, threads, reps, _p(stats)))
+
+
+def time_single_frame(payload, codec, threads: int, reps: int = 1, return_slots: bool = False):
+    """B1 as BASELINE.md section 2 words it: one frame per call through the single-frame shim; seconds for all reps."""
+    payload = np.ascontiguousarray(payload, dtype=np.uint8)
+    F_, C_, n = payload.shape
+    slots = np.zeros((C_,), dtype=FRAME_STATS)
+    t = float(lib().orc_time_single_frame(_p(payload), _p(np.ascontiguousarray(codec, np.uint8)), C_, F_, n, threads, reps, _p(slots)))
+    return (t, slots) if return_slots else t
 
 
 def time_byte_mean(payload, threads: int, reps: int = 1) -> float:
