@@ -47,6 +47,7 @@ BYTES_PER_SAMPLE = {"meter": (160 + 1 + 16) / 160.0, "store": (160 + 1 + 16 + 32
                     "depayload": (180 + 160 + 2 + 8) / 160.0,
                     "rtp": (192 + 1 + 16 + 8) / 160.0,           # fused: 192 B packet slot in, record + info out
                     "packets": (180 + 1 + 16 + 8) / 160.0,       # fused, packets packed at their natural 180 B stride
+                    "window": (180 + 1 + 16 + 8) / 160.0,        # the same + the ED-137 gated window and the silence run folded in the same pass (hold / probe / run summaries: < 0.1 % more)
                     "wav": (160 + 320) / 160.0,                  # 8(f) rank 2: payload in, [b, 0x00] file images out (+ 44 B per channel)
                     "encode": (320 + 1 + 160) / 160.0}           # a2: int16 in, code out    # 8(f) rank 1: 180 B packet in, dense payload + len + info out
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
@@ -66,7 +67,7 @@ def parse():
     ap.add_argument("--total-channels", type=int, default=0,
                     help="strong scaling: this many channels in total, split evenly over the ranks (SURVEY 8d: 524288 over 1/2/4/8 "
                          "GPUs); overrides --channels and reports \"scaling\": \"strong\"")
-    ap.add_argument("--mode", choices=["meter", "store", "roundtrip", "depayload", "rtp", "packets", "encode", "wav"], default="meter")
+    ap.add_argument("--mode", choices=["meter", "store", "roundtrip", "depayload", "rtp", "packets", "window", "encode", "wav"], default="meter")
     ap.add_argument("--variant", type=int, default=0,
                     help="igdsp_set_variant: 0 tuned default, 1 wave-per-frame, 2 chunk64, 3 chunk64 fat waves, 4 round trip through the compressor cell table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -204,12 +205,16 @@ def main():
         spec.append(("pcm_in", (F_, C_, n), I16, capi.IO_INPUT))
     if MODE == "rtp":
         spec.append(("slots", (F_, C_, 192), U8, capi.IO_INPUT))
-    if MODE == "packets":
+    if MODE in ("packets", "window"):
         spec.append(("slots", (F_, C_, 180), U8, capi.IO_INPUT))
     if MODE not in ("encode", "wav"):
         spec.append(("st", (F_ * C_ * 2,), I64, capi.IO_RECORD))               # igdsp_frame_stats[F][C]
-    if MODE in ("rtp", "packets", "depayload"):
+    if MODE in ("rtp", "packets", "window", "depayload"):
         spec.append(("info", (F_ * C_,), I64, capi.IO_RECORD))
+    if MODE == "window":
+        spec.append(("hold", (C_ * 4,), I64, capi.IO_RECORD))
+        spec.append(("probe", (C_,), I64, capi.IO_RECORD))
+        spec.append(("work", (C_ * 16,), I64, capi.IO_RECORD))                 # igdsp_window_work_bytes(C) = 8 segments x C x 16 B
     if MODE == "depayload":
         spec.append(("len", (F_ * C_,), I16, capi.IO_RECORD))
         spec.append(("dense", (F_, C_, n), U8, capi.IO_BULK))
@@ -261,6 +266,9 @@ def main():
                 else:                                                         # [F][C][180] ED-137 packets, PT 0, all full
                     t["slots"][:, :, 0] = 0x90
                     t["slots"][:, :, 1] = 0
+            if MODE == "window":
+                ctx.hold_reset(t["hold"], C_, stream=hs)
+                t["probe"].zero_()
             if MODE == "roundtrip":                                           # BASELINE configs[4]: mixed A-law / mu-law, D-speech
                 # D-speech: two-tone + noise, amplitude 1000*(1 + c mod 30), encoded with the oracle's encoder.  The
                 # generator is CPU test infrastructure, so a [F][480][160] tile (16 amplitude periods, both laws) is generated once
@@ -308,6 +316,9 @@ def main():
             ctx.decode_meter_rtp(t["slots"], d_cd, C_, F_, t["st"], info=t["info"], agg=agg, rank=rank, stream=hs)
         elif MODE == "packets":
             ctx.decode_meter_packets(t["slots"], None, d_cd, C_, F_, 180, 20, t["st"], info=t["info"], agg=agg, rank=rank, stream=hs)
+        elif MODE == "window":
+            win = ctx.window(t["hold"], gate_mode=capi.GATE_SQU_OR_PTT, probe=t["probe"], work=t["work"])
+            ctx.decode_meter_window(capi.PKT_PACKED, t["slots"], None, d_cd, None, C_, F_, 180, 20, t["st"], win, info=t["info"], agg=agg, rank=rank, stream=hs)
         elif MODE == "depayload":
             ctx.depayload(t["pk"], None, d_radio, C_, F_, 180, n, t["dense"], t["len"], t["info"], stream=hs)
         elif MODE == "roundtrip":
@@ -432,7 +443,7 @@ def main():
     value = total_samples / dt / 1e6
     bps = BYTES_PER_SAMPLE[args.mode] if n == N_SAMPLES else (n + 1 + 16 + {"store": 2 * n, "roundtrip": n}.get(args.mode, 0)) / n
     achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9
-    kernel_name = "k_encode_lut16" if args.mode == "encode" else "k_wav_expand16" if args.mode == "wav" else "k_meter_rtp64" if args.mode in ("rtp", "packets") else "k_depayload64" if args.mode == "depayload" else ("k_roundtrip_chunk64" if args.variant == 4 else "k_roundtrip_lut64" if n == N_SAMPLES else "k_roundtrip_strided") if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64" if n == N_SAMPLES else "k_meter_strided" if ((n >> 4) in (1, 4, 5, 6, 8, 10, 12, 15) and (n >> 2) & 3 != 3 and n not in (244, 248)) else "k_meter_image")
+    kernel_name = "k_encode_lut16" if args.mode == "encode" else "k_wav_expand16" if args.mode == "wav" else "k_meter_rtp64" if args.mode in ("rtp", "packets", "window") else "k_depayload64" if args.mode == "depayload" else ("k_roundtrip_chunk64" if args.variant == 4 else "k_roundtrip_lut64" if n == N_SAMPLES else "k_roundtrip_strided") if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64" if n == N_SAMPLES else "k_meter_strided" if ((n >> 4) in (1, 4, 5, 6, 8, 10, 12, 15) and (n >> 2) & 3 != 3 and n not in (244, 248)) else "k_meter_image")
 
     def frac_of(ms):
         return None if ms is None else round(samples_per_step_rank * bps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

@@ -16,7 +16,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libigdsp.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PT_PCMU, PT_PCMA, PT_R2S = 0, 8, 123
 SAMPLES_PER_FRAME = 160
 MAX_PAYLOAD = 256
@@ -42,6 +42,10 @@ CHAN_HOLD = np.dtype(
     align=True,
 )
 RTP_INFO = np.dtype([("ed137", "<u4"), ("payload_len", "<u2"), ("pt", "u1"), ("flags", "u1")], align=True)
+CHAN_PROBE = np.dtype([("run", "<u4"), ("alarms", "<u4")], align=True)
+GATE_ALWAYS, GATE_SQU, GATE_PTT, GATE_SQU_OR_PTT = 0, 1, 2, 3
+PKT_SLOTS, PKT_PACKED, PKT_MIXED = 0, 1, 2
+PROBE_ALARM = 500
 RTP_V2, RTP_X, RTP_MARKER, RTP_ED137_OK, RTP_KEEPALIVE, RTP_METERED, RTP_RUNT, RTP_OVERSIZE = 1, 2, 4, 8, 16, 32, 64, 128
 AGGREGATE = np.dtype({      # one 128-byte line per counter (include/igdsp.h); the padding is not exposed as fields
     "names": ["sumsq", "samples", "frames", "n_silent", "n_clipped", "byte_mean_sum", "peak_slot"],
@@ -54,6 +58,16 @@ AGGREGATE = np.dtype({      # one 128-byte line per counter (include/igdsp.h); t
 class Level(C.Structure):
     _fields_ = [("byte_mean", C.c_uint8), ("flags", C.c_uint8), ("peak", C.c_uint16), ("rms", C.c_float),
                 ("percent", C.c_int32), ("peak_hold", C.c_uint16), ("dropped", C.c_uint16), ("frames", C.c_uint32)]
+
+
+class Window(C.Structure):
+    """igdsp_window: the ED-137 gated window of igdsp_window_update / igdsp_decode_meter_window."""
+    _fields_ = [("gate_mode", C.c_uint32), ("probe_alarm", C.c_uint32), ("d_hold", C.c_void_p), ("d_gate", C.c_void_p),
+                ("d_probe", C.c_void_p), ("d_work", C.c_void_p)]
+
+
+class ChanProbe(C.Structure):
+    _fields_ = [("run", C.c_uint32), ("alarms", C.c_uint32)]
 
 
 IO_INPUT, IO_RECORD, IO_BULK = 0, 1, 2
@@ -91,6 +105,11 @@ PROTOTYPES = [
     ("igdsp_unmap_call", _int, [_vp, _i32]),
     ("igdsp_on_rtp_frame", _int, [_vp, _i32, C.c_uint8, _vp, _u32]),
     ("igdsp_flush", _int, [_vp, C.POINTER(_u32)]),
+    ("igdsp_flush_begin", _int, [_vp, C.POINTER(_u32)]),
+    ("igdsp_flush_end", _int, [_vp, _int]),
+    ("igdsp_set_ed137", _int, [_vp, _i32, _u32]),
+    ("igdsp_set_gate_mode", _int, [_vp, _u32]),
+    ("igdsp_get_probe", _int, [_vp, _u32, C.POINTER(ChanProbe)]),
     ("igdsp_poll", _int, [_vp, _u32, C.POINTER(Level)]),
     ("igdsp_poll_call", _int, [_vp, _i32, C.POINTER(Level)]),
     ("igdsp_reset_hold", _int, [_vp, _u32]),
@@ -105,6 +124,9 @@ PROTOTYPES = [
     ("igdsp_decode_meter_rtp", _int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
     ("igdsp_decode_meter_packets", _int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
     ("igdsp_decode_meter_packets_mixed", _int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
+    ("igdsp_window_work_bytes", C.c_size_t, [_u32]),
+    ("igdsp_window_update", _int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, C.POINTER(Window), _vp]),
+    ("igdsp_decode_meter_window", _int, [_vp, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, C.POINTER(Window), _vp]),
     ("igdsp_wav_expand", _int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _u64, _vp]),
     ("igdsp_g726_reorder", _int, [_vp, _vp, _vp, _u64, _int, _vp]),
     ("igdsp_gen_uniform", _int, [_vp, _vp, _u64, _u64, _u64, _vp]),
@@ -225,6 +247,29 @@ class Context:
         self._ck(self.L.igdsp_flush(self.h, C.byref(n)), "igdsp_flush")
         return n.value
 
+    def flush_begin(self) -> int:
+        n = _u32()
+        self._ck(self.L.igdsp_flush_begin(self.h, C.byref(n)), "igdsp_flush_begin")
+        return n.value
+
+    def flush_end(self, wait: bool = True) -> int:
+        """0 when the flush has been published, IGDSP_EBUSY (-16) when wait is False and the device has not finished."""
+        rc = self.L.igdsp_flush_end(self.h, 1 if wait else 0)
+        if rc not in (0, -16):
+            self._ck(rc, "igdsp_flush_end")
+        return rc
+
+    def set_ed137(self, call_id: int, value: int):
+        self._ck(self.L.igdsp_set_ed137(self.h, call_id, value & 0xFFFFFFFF), "igdsp_set_ed137")
+
+    def set_gate_mode(self, mode: int):
+        self._ck(self.L.igdsp_set_gate_mode(self.h, mode), "igdsp_set_gate_mode")
+
+    def get_probe(self, channel: int) -> ChanProbe:
+        p = ChanProbe()
+        self._ck(self.L.igdsp_get_probe(self.h, channel, C.byref(p)), "igdsp_get_probe")
+        return p
+
     def poll(self, channel: int) -> Level:
         lv = Level()
         self._ck(self.L.igdsp_poll(self.h, channel, C.byref(lv)), "igdsp_poll")
@@ -279,6 +324,21 @@ class Context:
     def decode_meter_packets_mixed(self, packets, sizes, codec, radio, C_, F_, stride, stats, info=None, agg=None, rank=0, stream=None):
         self._ck(self.L.igdsp_decode_meter_packets_mixed(self.h, _ptr(packets), _ptr(sizes), _ptr(codec), _ptr(radio), C_, F_, stride,
                                                          _ptr(stats), _ptr(info), _ptr(agg), rank, stream), "igdsp_decode_meter_packets_mixed")
+
+    # -- ED-137 gated window
+    @staticmethod
+    def window(hold, gate_mode=GATE_ALWAYS, gate=None, probe=None, work=None, probe_alarm=0) -> Window:
+        return Window(gate_mode, probe_alarm, _ptr(hold), _ptr(gate), _ptr(probe), _ptr(work))
+
+    def window_work_bytes(self, C_: int) -> int:
+        return int(self.L.igdsp_window_work_bytes(C_))
+
+    def window_update(self, stats, C_, F_, n, win: Window, info=None, length=None, stream=None):
+        self._ck(self.L.igdsp_window_update(self.h, _ptr(stats), _ptr(info), _ptr(length), C_, F_, n, C.byref(win), stream), "igdsp_window_update")
+
+    def decode_meter_window(self, layout, packets, sizes, codec, radio, C_, F_, stride, hdr, stats, win: Window, info=None, agg=None, rank=0, stream=None):
+        self._ck(self.L.igdsp_decode_meter_window(self.h, layout, _ptr(packets), _ptr(sizes), _ptr(codec), _ptr(radio), C_, F_, stride, hdr,
+                                                  _ptr(stats), _ptr(info), _ptr(agg), rank, C.byref(win), stream), "igdsp_decode_meter_window")
 
     def wav_expand(self, payload, C_, F_, n, files, file_stride, rate=8000, stream=None):
         self._ck(self.L.igdsp_wav_expand(self.h, _ptr(payload), C_, F_, n, rate, _ptr(files), file_stride, stream), "igdsp_wav_expand")

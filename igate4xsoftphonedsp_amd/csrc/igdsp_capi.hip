@@ -12,8 +12,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -23,9 +26,10 @@ using namespace igdsp;
 namespace {
 // Layout of the flush upload block (same offsets in the pinned host copy and in its device mirror; every section starts on
 // a 256-byte boundary).  Group A = whole 160-byte frames, dense at stride 160 (the tuned chunk kernel's layout); group B =
-// every other length, slots of 256 bytes with a length per frame (the general kernel).  A "run" = the consecutive records
-// of one channel inside a group: {channel, first record, count}.
-struct UploadLayout { size_t payA, payB, lenB, ptA, ptB, runA, runB, total; };
+// every other length, slots of 256 bytes with a length per frame (the general kernel).  seq = every staged frame in the
+// order its channel received it: {record id (group B: | 0x80000000), ED-137 word}; runs[c] = {first seq entry, count} of
+// channel c (count 0: nothing staged).
+struct UploadLayout { size_t payA, payB, lenB, ptA, ptB, seq, runs, total; };
 inline UploadLayout upload_layout(size_t max_frames, size_t max_channels)
 {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -36,8 +40,8 @@ inline UploadLayout upload_layout(size_t max_frames, size_t max_channels)
     L.lenB = o; o = up(o + max_frames * sizeof(uint16_t));
     L.ptA = o;  o = up(o + max_frames);
     L.ptB = o;  o = up(o + max_frames);
-    L.runA = o; o = up(o + max_channels * 3 * sizeof(uint32_t));
-    L.runB = o; o = up(o + max_channels * 3 * sizeof(uint32_t));
+    L.seq = o;  o = up(o + max_frames * 2 * sizeof(uint32_t));
+    L.runs = o; o = up(o + max_channels * 2 * sizeof(uint32_t));
     L.total = o;
     return L;
 }
@@ -49,7 +53,72 @@ inline void cpu_relax()
     asm volatile("yield");
 #endif
 }
+constexpr uint32_t kRecB = 0x80000000u;
+constexpr uint32_t kPoolMinChannels = 16384;            // below this one thread snapshots faster than a pool wakes up
+constexpr uint32_t kPoolMaxThreads = 8;
+
+// What one snapshot worker found in its channel range [c0, c1): its frames sit in ITS region of every section (frame index
+// c0 * kStageDepth onwards), so workers never touch each other's bytes.
+struct SnapPart { uint32_t c0 = 0, c1 = 0, nA = 0, nB = 0, nSeq = 0; };
 }  // namespace
+
+// A few persistent helper threads for the flush's snapshot at many channels.  run() hands part i to thread i (the caller takes
+// part 0) and returns when all are done.
+struct igdsp_ctx::SnapshotPool {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    uint64_t epoch = 0;
+    uint32_t pending = 0;
+    bool quit = false;
+    std::function<void(uint32_t)> job;
+
+    explicit SnapshotPool(uint32_t helpers)
+    {
+        for (uint32_t i = 0; i < helpers; ++i)
+            threads.emplace_back([this, i] {
+                uint64_t seen = 0;
+                for (;;) {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv_go.wait(lk, [&] { return quit || epoch != seen; });
+                    if (quit) return;
+                    seen = epoch;
+                    lk.unlock();
+                    job(i + 1);
+                    lk.lock();
+                    if (--pending == 0) cv_done.notify_one();
+                }
+            });
+    }
+    ~SnapshotPool()
+    {
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        cv_go.notify_all();
+        for (auto &t : threads) t.join();
+    }
+    void run(const std::function<void(uint32_t)> &fn)
+    {
+        { std::lock_guard<std::mutex> lk(m); job = fn; pending = (uint32_t)threads.size(); ++epoch; }
+        cv_go.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+
+// Read one channel's published state: copy out of the front set, retry if a flush_end moved it meanwhile (two flushes would
+// have to complete within the copy of ~60 bytes for a second retry).
+template <typename Fn>
+static inline void read_published(igdsp_ctx *ctx, Fn &&fn)
+{
+    for (;;) {
+        const uint64_t s1 = ctx->pub_seq.load(std::memory_order_acquire);
+        if (s1 & 1u) { cpu_relax(); continue; }                       // igdsp_reset_hold is rewriting the front set
+        fn(ctx->pub[ctx->front.load(std::memory_order_acquire)]);
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (ctx->pub_seq.load(std::memory_order_relaxed) == s1) return;
+    }
+}
 
 extern "C" {
 
@@ -76,29 +145,36 @@ int igdsp_create(igdsp_ctx **out, int device, uint32_t max_channels)
     for (auto &d : ctx->direct) d.store(kNoChan, std::memory_order_relaxed);
     ctx->slot_lock = std::vector<std::atomic_flag>(max_channels);
     for (auto &f : ctx->slot_lock) f.clear();
-    ctx->frames_seen.assign(max_channels, 0);
-
+    ctx->cur_ed137 = std::vector<std::atomic<uint32_t>>(max_channels);
+    ctx->frames_seen = std::vector<std::atomic<uint32_t>>(max_channels);
+    ctx->frames_dropped = std::vector<std::atomic<uint32_t>>(max_channels);
+    for (uint32_t c = 0; c < max_channels; ++c) { ctx->cur_ed137[c].store(0); ctx->frames_seen[c].store(0); ctx->frames_dropped[c].store(0); }
     ctx->head.assign(max_channels, 0);
     ctx->tail.assign(max_channels, 0);
-    ctx->frames_dropped.assign(max_channels, 0);
-    ctx->newest.assign(max_channels, 0);
     const size_t max_frames = (size_t)max_channels * kStageDepth;       // most frames one flush can take
     const size_t ring = max_frames * kSlot;
-    // upload block: [payload A: max_frames x 160][payload B: max_frames x 256][len B u16][pt A][pt B][runs A: 3 x u32][runs B: 3 x u32]
     ctx->up_bytes = upload_layout(max_frames, max_channels).total;
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->flush_done, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_ring, ring, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_rlen, max_frames * sizeof(uint16_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_rpt, max_frames, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&ctx->h_red, max_frames * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_up, ctx->up_bytes, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&ctx->h_stats, max_channels * sizeof(igdsp_frame_stats), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&ctx->h_fresh, max_frames * sizeof(igdsp_frame_stats), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&ctx->h_hold, max_channels * sizeof(igdsp_chan_hold), hipHostMallocDefault) == hipSuccess;
+    for (auto &pb : ctx->pub) {
+        ok = ok && hipHostMalloc((void **)&pb.last, max_channels * sizeof(igdsp_frame_stats), hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc((void **)&pb.hold, max_channels * sizeof(igdsp_chan_hold), hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc((void **)&pb.probe, max_channels * sizeof(igdsp_chan_probe), hipHostMallocDefault) == hipSuccess;
+    }
     ok = ok && hipMalloc((void **)&ctx->d_up, ctx->up_bytes) == hipSuccess;
-    ok = ok && hipMalloc((void **)&ctx->d_stats, max_frames * sizeof(igdsp_frame_stats)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_stats, 2 * max_frames * sizeof(igdsp_frame_stats)) == hipSuccess;   // group A | group B
+    ok = ok && hipMalloc((void **)&ctx->d_last, max_channels * sizeof(igdsp_frame_stats)) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_hold, max_channels * sizeof(igdsp_chan_hold)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_probe, max_channels * sizeof(igdsp_chan_probe)) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_queues, kQueueRing * 32u * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(ctx->d_queues, 0, kQueueRing * 32u * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(ctx->d_last, 0, max_channels * sizeof(igdsp_frame_stats)) == hipSuccess;
+    ok = ok && hipMemset(ctx->d_probe, 0, max_channels * sizeof(igdsp_chan_probe)) == hipSuccess;
     if (const char *e = std::getenv("IGDSP_GLOBAL_QUEUE")) ctx->global_queue = std::atoi(e) != 0;
     if (!ok) {
         igdsp_destroy(ctx);
@@ -108,12 +184,21 @@ int igdsp_create(igdsp_ctx **out, int device, uint32_t max_channels)
         igdsp_destroy(ctx);
         return IGDSP_EDEVICE;
     }
-    std::memset(ctx->h_stats, 0, max_channels * sizeof(igdsp_frame_stats));
-    if (launch_hold_reset(ctx->d_hold, max_channels, nullptr, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(ctx->h_hold, ctx->d_hold, max_channels * sizeof(igdsp_chan_hold), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    bool up = launch_hold_reset(ctx->d_hold, max_channels, nullptr, ctx->stream) == hipSuccess;
+    for (auto &pb : ctx->pub) {
+        std::memset(pb.last, 0, max_channels * sizeof(igdsp_frame_stats));
+        std::memset(pb.probe, 0, max_channels * sizeof(igdsp_chan_probe));
+        up = up && hipMemcpyAsync(pb.hold, ctx->d_hold, max_channels * sizeof(igdsp_chan_hold), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    }
+    if (!up || hipStreamSynchronize(ctx->stream) != hipSuccess) {
         igdsp_destroy(ctx);
         return IGDSP_EDEVICE;
+    }
+    if (max_channels >= kPoolMinChannels) {
+        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+        uint32_t threads = std::min(std::min(kPoolMaxThreads, std::max(1u, hw / 2u)), max_channels / (kPoolMinChannels / 2u));
+        if (const char *e = std::getenv("IGDSP_FLUSH_THREADS")) threads = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
+        if (threads > 1u) ctx->pool = new (std::nothrow) igdsp_ctx::SnapshotPool(threads - 1u);
     }
     *out = ctx;
     return IGDSP_OK;
@@ -122,11 +207,14 @@ int igdsp_create(igdsp_ctx **out, int device, uint32_t max_channels)
 int igdsp_destroy(igdsp_ctx *ctx)
 {
     if (!ctx) return IGDSP_OK;                       // tolerate NULL like the reference's setters (TransportAdapter.cpp:135-223)
+    delete ctx->pool;
     if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
-    void *hosts[] = {ctx->h_ring, ctx->h_rlen, ctx->h_rpt, ctx->h_up, ctx->h_stats, ctx->h_fresh, ctx->h_hold};
+    if (ctx->flush_done) (void)hipEventDestroy(ctx->flush_done);
+    void *hosts[] = {ctx->h_ring, ctx->h_rlen, ctx->h_rpt, ctx->h_red, ctx->h_up, ctx->pub[0].last, ctx->pub[0].hold, ctx->pub[0].probe,
+                     ctx->pub[1].last, ctx->pub[1].hold, ctx->pub[1].probe};
     for (void *p : hosts) if (p) (void)hipHostFree(p);
-    void *devs[] = {ctx->d_up, ctx->d_stats, ctx->d_hold, ctx->d_queues};
+    void *devs[] = {ctx->d_up, ctx->d_stats, ctx->d_last, ctx->d_hold, ctx->d_probe, ctx->d_queues};
     for (void *p : devs) if (p) (void)hipFree(p);
     delete ctx;
     return IGDSP_OK;
@@ -190,13 +278,14 @@ int igdsp_on_rtp_frame(igdsp_ctx *ctx, int32_t call_id, uint8_t pt, const uint8_
     int rc = IGDSP_OK;
     if (ctx->head[ch] - ctx->tail[ch] == kStageDepth) {                 // the owner thread is > 160 ms late: the oldest frame goes
         ctx->tail[ch] += 1;
-        ctx->frames_dropped[ch] += 1;
+        ctx->frames_dropped[ch].fetch_add(1, std::memory_order_relaxed);
         rc = IGDSP_EBUSY;
     }
     const size_t slot = (size_t)(ctx->head[ch] % kStageDepth) * ctx->max_channels + ch;   // slot-major: the flush walks each slot plane sequentially
     std::memcpy(ctx->h_ring + slot * kSlot, payload, payloadlen);
     ctx->h_rlen[slot] = (uint16_t)payloadlen;
     ctx->h_rpt[slot] = pt;
+    ctx->h_red[slot] = ctx->cur_ed137[ch].load(std::memory_order_relaxed);
     ctx->head[ch] += 1;
     lk.clear(std::memory_order_release);
     uint32_t hw = ctx->hi_water.load(std::memory_order_relaxed);
@@ -204,98 +293,185 @@ int igdsp_on_rtp_frame(igdsp_ctx *ctx, int32_t call_id, uint8_t pt, const uint8_
     return rc;
 }
 
+// setIncomingED137Value (roip_ed137.h:273): the word the call's frames carry from now on
+int igdsp_set_ed137(igdsp_ctx *ctx, int32_t call_id, uint32_t ed137_value)
+{
+    if (!ctx) return IGDSP_EINVAL;
+    const uint32_t ch = lookup(ctx, call_id);
+    if (ch == kNoChan) return IGDSP_ENOENT;
+    ctx->cur_ed137[ch].store(ed137_value, std::memory_order_relaxed);
+    return IGDSP_OK;
+}
+
+int igdsp_set_gate_mode(igdsp_ctx *ctx, uint32_t gate_mode)
+{
+    if (!ctx || gate_mode > IGDSP_GATE_SQU_OR_PTT) return IGDSP_EINVAL;
+    ctx->gate_mode.store(gate_mode, std::memory_order_relaxed);
+    return IGDSP_OK;
+}
+
+// One worker's share of the snapshot: every channel of [part.c0, part.c1), staged frames oldest first, compacted into the
+// worker's own region of the upload block, under the channel's flag.
+static void snapshot_part(igdsp_ctx *ctx, const UploadLayout &L, SnapPart &part)
+{
+    uint8_t *up = ctx->h_up;
+    uint16_t *lenB = reinterpret_cast<uint16_t *>(up + L.lenB);
+    uint32_t *seq = reinterpret_cast<uint32_t *>(up + L.seq), *runs = reinterpret_cast<uint32_t *>(up + L.runs);
+    const uint32_t base = part.c0 * kStageDepth;                       // first frame index of this worker's regions
+    uint32_t nA = 0, nB = 0, nS = 0;
+    for (uint32_t c = part.c0; c < part.c1; ++c) {
+        std::atomic_flag &lk = ctx->slot_lock[c];
+        while (lk.test_and_set(std::memory_order_acquire)) cpu_relax();
+        const uint32_t t0 = ctx->tail[c], h0 = ctx->head[c];
+        const uint32_t s0 = nS;
+        for (uint32_t k = t0; k != h0; ++k) {
+            const size_t slot = (size_t)(k % kStageDepth) * ctx->max_channels + c;
+            const uint16_t l = ctx->h_rlen[slot];
+            uint32_t id;
+            if (l == IGDSP_SAMPLES_PER_FRAME) {
+                id = base + nA++;
+                std::memcpy(up + L.payA + (size_t)id * IGDSP_SAMPLES_PER_FRAME, ctx->h_ring + slot * kSlot, l);
+                up[L.ptA + id] = ctx->h_rpt[slot];
+            } else {
+                const uint32_t ib = base + nB++;
+                std::memcpy(up + L.payB + (size_t)ib * kSlot, ctx->h_ring + slot * kSlot, l);
+                lenB[ib] = l;
+                up[L.ptB + ib] = ctx->h_rpt[slot];
+                id = ib | kRecB;
+            }
+            seq[2 * (size_t)(base + nS)] = id;
+            seq[2 * (size_t)(base + nS) + 1] = ctx->h_red[slot];
+            ++nS;
+        }
+        ctx->tail[c] = h0;
+        lk.clear(std::memory_order_release);
+        runs[2 * (size_t)c] = base + s0;
+        runs[2 * (size_t)c + 1] = nS - s0;
+        if (h0 != t0) ctx->frames_seen[c].fetch_add(h0 - t0, std::memory_order_relaxed);
+    }
+    part.nA = nA; part.nB = nB; part.nSeq = nS;
+}
+
+static int flush_end_locked(igdsp_ctx *ctx, int wait)
+{
+    if (!ctx->flush_open) return IGDSP_OK;
+    if (!wait) {
+        const hipError_t q = hipEventQuery(ctx->flush_done);
+        if (q == hipErrorNotReady) return IGDSP_EBUSY;
+        if (q != hipSuccess) return fail(ctx, IGDSP_EDEVICE, "hipEventQuery(flush_done)", q);
+    } else {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->flush_done));
+    }
+    // the back set is complete: make it the front set.  Readers that were half way through the old one notice pub_seq moving.
+    ctx->front.store(ctx->front.load(std::memory_order_relaxed) ^ 1u, std::memory_order_release);
+    ctx->pub_seq.fetch_add(2, std::memory_order_release);
+    ctx->flush_open = false;
+    return IGDSP_OK;
+}
+
+static int flush_begin_locked(igdsp_ctx *ctx, uint32_t *n_frames_out)
+{
+    if (int rc = flush_end_locked(ctx, 1)) return rc;               // one flush at a time: the upload block is single
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t nch = ctx->hi_water.load(std::memory_order_relaxed);
+    if (n_frames_out) *n_frames_out = 0;
+    if (nch == 0) return IGDSP_OK;
+    const size_t max_frames = (size_t)ctx->max_channels * kStageDepth;
+    const UploadLayout L = upload_layout(max_frames, ctx->max_channels);
+    // 1. snapshot every channel's staged frames (oldest first) into the upload block, compacted per worker region
+    SnapPart parts[kPoolMaxThreads * 8];
+    uint32_t n_parts = 1;
+    if (ctx->pool && nch >= kPoolMinChannels) n_parts = std::min<uint32_t>((uint32_t)ctx->pool->threads.size() + 1u, kPoolMaxThreads * 8u);
+    for (uint32_t i = 0; i < n_parts; ++i) { parts[i].c0 = (uint32_t)((uint64_t)nch * i / n_parts); parts[i].c1 = (uint32_t)((uint64_t)nch * (i + 1) / n_parts); }
+    if (n_parts == 1) snapshot_part(ctx, L, parts[0]);
+    else ctx->pool->run([&](uint32_t i) { if (i < n_parts) snapshot_part(ctx, L, parts[i]); });
+    uint32_t staged = 0, endA = 0, endB = 0, endS = 0;
+    for (uint32_t i = 0; i < n_parts; ++i) {
+        staged += parts[i].nSeq;
+        if (parts[i].nA) endA = parts[i].c0 * kStageDepth + parts[i].nA;
+        if (parts[i].nB) endB = parts[i].c0 * kStageDepth + parts[i].nB;
+        if (parts[i].nSeq) endS = parts[i].c0 * kStageDepth + parts[i].nSeq;
+    }
+    if (n_frames_out) *n_frames_out = staged;
+    if (staged == 0) return IGDSP_OK;
+    // 2. upload what is used: the payload regions per worker (the big ones), the small sections as one span each; meter group A
+    //    and group B over their spans (frames between two workers' regions are stale bytes: their records are never looked at),
+    //    fold every channel's frames in arrival order, download the per-channel state into the back set
+    hipStream_t s = ctx->stream;
+    uint8_t *up = ctx->h_up, *d = ctx->d_up;
+    auto copy = [&](size_t off, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpyAsync(d + off, up + off, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+    };
+    for (uint32_t i = 0; i < n_parts; ++i) {
+        const size_t base = (size_t)parts[i].c0 * kStageDepth;
+        HIP_TRY(ctx, copy(L.payA + base * IGDSP_SAMPLES_PER_FRAME, (size_t)parts[i].nA * IGDSP_SAMPLES_PER_FRAME));
+        HIP_TRY(ctx, copy(L.payB + base * kSlot, (size_t)parts[i].nB * kSlot));
+    }
+    HIP_TRY(ctx, copy(L.ptA, endA));
+    HIP_TRY(ctx, copy(L.ptB, endB));
+    HIP_TRY(ctx, copy(L.lenB, (size_t)endB * sizeof(uint16_t)));
+    HIP_TRY(ctx, copy(L.seq, (size_t)endS * 2 * sizeof(uint32_t)));
+    HIP_TRY(ctx, copy(L.runs, (size_t)nch * 2 * sizeof(uint32_t)));
+    // records: group A's at d_stats[id], group B's at d_stats[max_frames + id] (ids are region-based, so each group may reach max_frames)
+    igdsp_frame_stats *stA = ctx->d_stats, *stB = ctx->d_stats + max_frames;
+    if (endA)   // whole 160-byte frames, dense: the chunk kernel takes every 64, the general kernel the < 64 left over
+        HIP_TRY(ctx, launch_decode_meter(cfg_of(ctx, s), 0, d + L.payA, d + L.ptA, nullptr, endA, 1, IGDSP_SAMPLES_PER_FRAME, stA, nullptr, nullptr, 0, s));
+    for (uint32_t i = 0; i < n_parts; ++i)   // every other length (rare): 256-byte slots with a length per frame, one launch per region that has any
+        if (parts[i].nB) {
+            const size_t base = (size_t)parts[i].c0 * kStageDepth;
+            HIP_TRY(ctx, launch_decode_meter(cfg_of(ctx, s), 1, d + L.payB + base * kSlot, d + L.ptB + base, reinterpret_cast<const uint16_t *>(d + L.lenB) + base,
+                                             parts[i].nB, 1, kSlot, stB + base, nullptr, nullptr, 0, s));
+        }
+    HIP_TRY(ctx, launch_flush_fold(stA, stB, reinterpret_cast<const uint16_t *>(d + L.lenB), reinterpret_cast<const uint2 *>(d + L.seq),
+                                   reinterpret_cast<const uint2 *>(d + L.runs), nch, ctx->gate_mode.load(std::memory_order_relaxed), IGDSP_PROBE_ALARM,
+                                   ctx->d_hold, ctx->d_probe, ctx->d_last, s));
+    const igdsp_ctx::Published &back = ctx->pub[ctx->front.load(std::memory_order_relaxed) ^ 1u];
+    HIP_TRY(ctx, hipMemcpyAsync(back.last, ctx->d_last, (size_t)nch * sizeof(igdsp_frame_stats), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(back.hold, ctx->d_hold, (size_t)nch * sizeof(igdsp_chan_hold), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(back.probe, ctx->d_probe, (size_t)nch * sizeof(igdsp_chan_probe), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->flush_done, s));
+    ctx->flush_open = true;
+    ctx->flush_nch = nch;
+    return IGDSP_OK;
+}
+
+int igdsp_flush_begin(igdsp_ctx *ctx, uint32_t *n_frames_out)
+{
+    if (!ctx) return IGDSP_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->flush_mu);
+    return flush_begin_locked(ctx, n_frames_out);
+}
+
+int igdsp_flush_end(igdsp_ctx *ctx, int wait)
+{
+    if (!ctx) return IGDSP_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->flush_mu);
+    return flush_end_locked(ctx, wait);
+}
+
 int igdsp_flush(igdsp_ctx *ctx, uint32_t *n_frames_out)
 {
     if (!ctx) return IGDSP_EINVAL;
     std::lock_guard<std::mutex> g(ctx->flush_mu);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const uint32_t nch = ctx->hi_water.load(std::memory_order_relaxed);
-    const size_t max_frames = (size_t)ctx->max_channels * kStageDepth;
-    const UploadLayout L = upload_layout(max_frames, ctx->max_channels);
-    uint8_t *up = ctx->h_up;
-    uint16_t *lenB = reinterpret_cast<uint16_t *>(up + L.lenB);
-    uint32_t *runA = reinterpret_cast<uint32_t *>(up + L.runA), *runB = reinterpret_cast<uint32_t *>(up + L.runB);
-    // 1. snapshot every channel's staged frames (oldest first) into the upload block, compacted, under the channel's flag
-    uint32_t nA = 0, nB = 0, nrA = 0, nrB = 0;
-    constexpr uint32_t kNone = 0xFFFFFFFFu, kB = 0x80000000u;
-    for (uint32_t c = 0; c < nch; ++c) {
-        std::atomic_flag &lk = ctx->slot_lock[c];
-        while (lk.test_and_set(std::memory_order_acquire)) cpu_relax();
-        const uint32_t t0 = ctx->tail[c], h0 = ctx->head[c];
-        uint32_t a0 = nA, b0 = nB, newest = kNone;
-        for (uint32_t k = t0; k != h0; ++k) {
-            const size_t slot = (size_t)(k % kStageDepth) * ctx->max_channels + c;
-            const uint16_t l = ctx->h_rlen[slot];
-            if (l == IGDSP_SAMPLES_PER_FRAME) {
-                std::memcpy(up + L.payA + (size_t)nA * IGDSP_SAMPLES_PER_FRAME, ctx->h_ring + slot * kSlot, l);
-                up[L.ptA + nA] = ctx->h_rpt[slot];
-                newest = nA++;
-            } else {
-                std::memcpy(up + L.payB + (size_t)nB * kSlot, ctx->h_ring + slot * kSlot, l);
-                lenB[nB] = l;
-                up[L.ptB + nB] = ctx->h_rpt[slot];
-                newest = kB | nB++;
-            }
-        }
-        ctx->tail[c] = h0;
-        lk.clear(std::memory_order_release);
-        if (nA != a0) { runA[3 * nrA] = c; runA[3 * nrA + 1] = a0; runA[3 * nrA + 2] = nA - a0; ++nrA; }
-        if (nB != b0) { runB[3 * nrB] = c; runB[3 * nrB + 1] = b0; runB[3 * nrB + 2] = nB - b0; ++nrB; }
-        ctx->newest[c] = newest;
-        ctx->frames_seen[c] += h0 - t0;
-    }
-    const uint32_t staged = nA + nB;
-    if (n_frames_out) *n_frames_out = staged;
-    if (staged == 0) return IGDSP_OK;
-    // 2. one upload (everything up to the last used section; the block is ~1.7 KB per staged frame at most), meter, fold, download
-    hipStream_t s = ctx->stream;
-    uint8_t *d = ctx->d_up;
-    auto copy_section = [&](size_t off, size_t bytes) -> hipError_t {
-        return bytes ? hipMemcpyAsync(d + off, up + off, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
-    };
-    HIP_TRY(ctx, copy_section(L.payA, (size_t)nA * IGDSP_SAMPLES_PER_FRAME));
-    HIP_TRY(ctx, copy_section(L.payB, (size_t)nB * kSlot));
-    HIP_TRY(ctx, copy_section(L.lenB, (size_t)nB * sizeof(uint16_t)));
-    HIP_TRY(ctx, copy_section(L.ptA, nA));
-    HIP_TRY(ctx, copy_section(L.ptB, nB));
-    HIP_TRY(ctx, copy_section(L.runA, (size_t)nrA * 3 * sizeof(uint32_t)));
-    HIP_TRY(ctx, copy_section(L.runB, (size_t)nrB * 3 * sizeof(uint32_t)));
-    // records: group A first, then group B.  Each staged frame is its own "channel" of a one-frame batch (its codec = its PT).
-    igdsp_frame_stats *stA = ctx->d_stats, *stB = ctx->d_stats + nA;
-    if (nA) {   // whole 160-byte frames, dense: the chunk kernel takes every 64, the general kernel the < 64 left over
-        HIP_TRY(ctx, launch_decode_meter(cfg_of(ctx, s), 0, d + L.payA, d + L.ptA, nullptr, nA, 1, IGDSP_SAMPLES_PER_FRAME, stA, nullptr, nullptr, 0, s));
-        HIP_TRY(ctx, launch_hold_fold_runs(stA, nullptr, IGDSP_SAMPLES_PER_FRAME, reinterpret_cast<const uint32_t *>(d + L.runA), nrA, ctx->d_hold, s));
-    }
-    if (nB) {   // every other length: 256-byte slots with a length per frame
-        HIP_TRY(ctx, launch_decode_meter(cfg_of(ctx, s), 1, d + L.payB, d + L.ptB, reinterpret_cast<const uint16_t *>(d + L.lenB), nB, 1, kSlot, stB, nullptr, nullptr, 0, s));
-        HIP_TRY(ctx, launch_hold_fold_runs(stB, reinterpret_cast<const uint16_t *>(d + L.lenB), kSlot, reinterpret_cast<const uint32_t *>(d + L.runB), nrB, ctx->d_hold, s));
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fresh, ctx->d_stats, (size_t)staged * sizeof(igdsp_frame_stats), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hold, ctx->d_hold, nch * sizeof(igdsp_chan_hold), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    // 3. a channel's level = the record of its newest frame; a channel with nothing staged keeps its previous level
-    for (uint32_t c = 0; c < nch; ++c) {
-        const uint32_t nw = ctx->newest[c];
-        if (nw == kNone) continue;
-        ctx->h_stats[c] = ctx->h_fresh[(nw & kB) ? nA + (nw & ~kB) : nw];
-    }
-    return IGDSP_OK;
+    if (int rc = flush_begin_locked(ctx, n_frames_out)) return rc;
+    return flush_end_locked(ctx, 1);
 }
 
 int igdsp_poll(igdsp_ctx *ctx, uint32_t channel, igdsp_level *out)
 {
     if (!ctx || !out) return IGDSP_EINVAL;
     if (channel >= ctx->max_channels) return IGDSP_ERANGE;
-    std::lock_guard<std::mutex> g(ctx->flush_mu);
-    const igdsp_frame_stats &s = ctx->h_stats[channel];
+    igdsp_frame_stats s;
+    uint16_t peak_hold = 0;
+    read_published(ctx, [&](const igdsp_ctx::Published &p) { s = p.last[channel]; peak_hold = p.hold[channel].peak_hold; });
     out->byte_mean = s.byte_mean;
     out->flags = s.flags;
     out->peak = s.peak;
     out->rms = s.rms;
     out->percent = (int32_t)(float)(((double)s.rms * 100.0) / (double)IGDSP_METER_FULL_SCALE);   // audiometer.cpp:30-31
-    out->peak_hold = ctx->h_hold[channel].peak_hold;
-    out->dropped = (uint16_t)std::min<uint32_t>(ctx->frames_dropped[channel], 65535u);
-    out->frames = ctx->frames_seen[channel];
+    out->peak_hold = peak_hold;
+    out->dropped = (uint16_t)std::min<uint32_t>(ctx->frames_dropped[channel].load(std::memory_order_relaxed), 65535u);
+    out->frames = ctx->frames_seen[channel].load(std::memory_order_relaxed);
     return IGDSP_OK;
 }
 
@@ -312,12 +488,18 @@ int igdsp_reset_hold(igdsp_ctx *ctx, uint32_t channel)
     if (!ctx) return IGDSP_EINVAL;
     if (channel != 0xFFFFFFFFu && channel >= ctx->max_channels) return IGDSP_ERANGE;
     std::lock_guard<std::mutex> g(ctx->flush_mu);
+    if (int rc = flush_end_locked(ctx, 1)) return rc;                  // a flush under way folds into the window being reset: finish it first
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t c0 = (channel == 0xFFFFFFFFu) ? 0 : channel;
     const uint32_t cn = (channel == 0xFFFFFFFFu) ? ctx->max_channels : 1;
     HIP_TRY(ctx, launch_hold_reset(ctx->d_hold + c0, cn, nullptr, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hold + c0, ctx->d_hold + c0, cn * sizeof(igdsp_chan_hold), hipMemcpyDeviceToHost, ctx->stream));
+    // both published sets show the reset window at once (no flush is open, so nothing else writes them)
+    const uint32_t f = ctx->front.load(std::memory_order_relaxed);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pub[f ^ 1u].hold + c0, ctx->d_hold + c0, cn * sizeof(igdsp_chan_hold), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pub_seq.fetch_add(1, std::memory_order_acq_rel);             // odd: readers wait
+    std::memcpy(ctx->pub[f].hold + c0, ctx->pub[f ^ 1u].hold + c0, cn * sizeof(igdsp_chan_hold));
+    ctx->pub_seq.fetch_add(1, std::memory_order_release);
     return IGDSP_OK;
 }
 
@@ -325,8 +507,15 @@ int igdsp_get_hold(igdsp_ctx *ctx, uint32_t channel, igdsp_chan_hold *out)
 {
     if (!ctx || !out) return IGDSP_EINVAL;
     if (channel >= ctx->max_channels) return IGDSP_ERANGE;
-    std::lock_guard<std::mutex> g(ctx->flush_mu);
-    *out = ctx->h_hold[channel];
+    read_published(ctx, [&](const igdsp_ctx::Published &p) { *out = p.hold[channel]; });
+    return IGDSP_OK;
+}
+
+int igdsp_get_probe(igdsp_ctx *ctx, uint32_t channel, igdsp_chan_probe *out)
+{
+    if (!ctx || !out) return IGDSP_EINVAL;
+    if (channel >= ctx->max_channels) return IGDSP_ERANGE;
+    read_published(ctx, [&](const igdsp_ctx::Published &p) { *out = p.probe[channel]; });
     return IGDSP_OK;
 }
 
@@ -482,6 +671,86 @@ int igdsp_decode_meter_packets_mixed(igdsp_ctx *ctx, const uint8_t *d_packets, c
     return IGDSP_OK;
 }
 
+// ---------------------------------------------------------------- ED-137 gated window (last clause)
+size_t igdsp_window_work_bytes(uint32_t n_channels) { return (size_t)kWinMaxSeg * n_channels * sizeof(uint4); }
+
+static int check_window(igdsp_ctx *ctx, const igdsp_window *win)
+{
+    if (!win || !win->d_hold || win->gate_mode > IGDSP_GATE_SQU_OR_PTT) return IGDSP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(win->d_hold) & 7u) || (reinterpret_cast<uintptr_t>(win->d_probe) & 3u) || (reinterpret_cast<uintptr_t>(win->d_work) & 15u))
+        return fail(ctx, IGDSP_EINVAL, "igdsp_window: d_hold 8-byte, d_probe 4-byte, d_work 16-byte aligned");
+    return IGDSP_OK;
+}
+
+int igdsp_window_update(igdsp_ctx *ctx, const igdsp_frame_stats *d_stats, const igdsp_rtp_info *d_info, const uint16_t *d_len,
+                        uint32_t C, uint32_t F, uint32_t n, const igdsp_window *win, void *stream)
+{
+    if (!ctx) return IGDSP_EINVAL;
+    if (int rc = check_window(ctx, win)) return rc;
+    if ((uint64_t)C * F == 0) return IGDSP_OK;
+    if (!d_stats) return IGDSP_EINVAL;
+    if (int rc = check_shape(C, F, n)) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_window_update(d_stats, d_info, d_len, C, F, n, win->gate_mode, win->probe_alarm ? win->probe_alarm : IGDSP_PROBE_ALARM,
+                                      win->d_hold, win->d_gate, win->d_probe, pick(ctx, stream)));
+    return IGDSP_OK;
+}
+
+int igdsp_decode_meter_window(igdsp_ctx *ctx, uint32_t layout, const uint8_t *d_packets, const uint16_t *d_sizes, const uint8_t *d_codec,
+                              const uint8_t *d_radio, uint32_t C, uint32_t F, uint32_t pkt_stride, uint32_t hdr_bytes,
+                              igdsp_frame_stats *d_stats, igdsp_rtp_info *d_info, igdsp_aggregate *d_agg, uint32_t rank,
+                              const igdsp_window *win, void *stream)
+{
+    if (!ctx || layout > IGDSP_PKT_MIXED) return IGDSP_EINVAL;
+    if (int rc = check_window(ctx, win)) return rc;
+    if ((uint64_t)C * F == 0) return IGDSP_OK;
+    if (!d_packets || !d_codec || !d_stats || rank >= IGDSP_AGG_MAX_RANKS) return IGDSP_EINVAL;
+    if (layout == IGDSP_PKT_MIXED && !d_radio) return IGDSP_EINVAL;
+    if (int rc = check_shape(C, F, IGDSP_SAMPLES_PER_FRAME)) return rc;
+    // the argument rules of the three fused entries
+    uint32_t stride = 0, hdr = 20;
+    const uint8_t *radio = nullptr;
+    const uint16_t *sizes = nullptr;
+    if (layout == IGDSP_PKT_SLOTS) {
+        if (reinterpret_cast<uintptr_t>(d_packets) & 15u) return fail(ctx, IGDSP_EINVAL, "decode_meter_window: slots need 16-byte alignment");
+    } else {
+        stride = pkt_stride; sizes = d_sizes;
+        if (layout == IGDSP_PKT_PACKED) {
+            if (hdr_bytes != 12u && hdr_bytes != 20u) return IGDSP_EINVAL;
+            hdr = hdr_bytes;
+        } else { hdr = 12; radio = d_radio; }
+        const uint32_t need = (layout == IGDSP_PKT_MIXED ? 20u : hdr) + IGDSP_SAMPLES_PER_FRAME;
+        if (pkt_stride < need || pkt_stride < 20u || (pkt_stride & 3u) || pkt_stride > 2048u || (uint64_t)C * F * pkt_stride > 0xFFFFFFFFull * 4ull ||
+            (reinterpret_cast<uintptr_t>(d_packets) & 3u) || (reinterpret_cast<uintptr_t>(d_sizes) & 1u))
+            return IGDSP_EINVAL;
+    }
+    if (((uint64_t)C * F) % 64u || (reinterpret_cast<uintptr_t>(d_stats) & 15u) || (reinterpret_cast<uintptr_t>(d_info) & 7u))
+        return fail(ctx, IGDSP_EINVAL, "decode_meter_window needs C*F % 64 == 0, 16-byte aligned stats, 8-byte aligned info");
+    const uint32_t alarm = win->probe_alarm ? win->probe_alarm : IGDSP_PROBE_ALARM;
+    hipStream_t s = pick(ctx, stream);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (C % 64u == 0u && (win->d_probe == nullptr || win->d_work != nullptr)) {
+        // channel-group-major fused kernel: the windows live in registers; at least one unit per resident wave, a segment is
+        // never shorter than 8 frames nor longer than 65 535 (silent / clipped counts of a unit are 16 bits)
+        igdsp::WinArgs w;
+        w.hold = win->d_hold; w.gate = win->d_gate; w.work = win->d_probe ? static_cast<uint4 *>(win->d_work) : nullptr;
+        w.gate_mode = win->gate_mode; w.alarm = alarm; w.n_groups = C / 64u; w.F = F;
+        const uint32_t want = (uint32_t)ctx->cus * 12u;
+        uint32_t n_seg = w.n_groups >= want ? 1u : (want + w.n_groups - 1u) / w.n_groups;
+        if (const char *e = std::getenv("IGDSP_WIN_NSEG")) n_seg = (uint32_t)std::max(1, std::atoi(e));   // experiments
+        n_seg = std::max(1u, std::min(std::min(n_seg, kWinMaxSeg), std::max(1u, F / 8u)));
+        if (F / n_seg > 65535u) return fail(ctx, IGDSP_ERANGE, "decode_meter_window: more than 8 x 65535 frames per launch");
+        w.n_seg = n_seg;
+        HIP_TRY(ctx, launch_decode_meter_rtp(cfg_of(ctx, s), d_packets, sizes, d_codec, C, F, stride, hdr, d_stats, d_info, d_agg, rank, s, radio, &w));
+        if (win->d_probe) HIP_TRY(ctx, launch_window_finish(w.work, C, n_seg, alarm, win->d_probe, s));
+        return IGDSP_OK;
+    }
+    // other channel counts: the plain fused kernel, then the record-wise window fold on the same stream
+    if (!d_info) return fail(ctx, IGDSP_EINVAL, "decode_meter_window: channel counts that are not multiples of 64 (or probe tracking without d_work) need d_info");
+    HIP_TRY(ctx, launch_decode_meter_rtp(cfg_of(ctx, s), d_packets, sizes, d_codec, C, F, stride, hdr, d_stats, d_info, d_agg, rank, s, radio));
+    HIP_TRY(ctx, launch_window_update(d_stats, d_info, nullptr, C, F, IGDSP_SAMPLES_PER_FRAME, win->gate_mode, alarm, win->d_hold, win->d_gate, win->d_probe, s));
+    return IGDSP_OK;
+}
 
 int igdsp_wav_expand(igdsp_ctx *ctx, const uint8_t *d_payload, uint32_t C, uint32_t F, uint32_t n, uint32_t rate,
                      uint8_t *d_files, uint64_t file_stride, void *stream)

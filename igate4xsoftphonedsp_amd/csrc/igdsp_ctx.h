@@ -43,28 +43,45 @@ struct igdsp_ctx {
     std::unordered_map<int32_t, uint32_t> far;
     std::mutex far_mu;
 
-    // staging (host pinned): a ring of kStageDepth frames per channel, ring[slot][c][256] + rlen / rpt per slot (slot-major: the
+    // staging (host pinned): a ring of kStageDepth frames per channel, ring[slot][c][256] + rlen / rpt / red per slot (slot-major: the
     // frames all calls staged at the same tick position sit next to each other, so the flush reads sequentially); head counts frames
-    // written, tail frames taken by igdsp_flush (head - tail <= kStageDepth).  tp_adapter::payload_buff[256] semantics per slot
+    // written, tail frames taken by a flush (head - tail <= kStageDepth).  tp_adapter::payload_buff[256] semantics per slot
     // (TransportAdapter.h:66): the reference's hook runs on EVERY frame (TransportAdapter.cpp:303), so every frame is kept.
+    // red = the call's ED-137 word when the frame was staged (igdsp_set_ed137 = setIncomingED137Value, roip_ed137.h:273).
     uint8_t *h_ring = nullptr;
     uint16_t *h_rlen = nullptr;
     uint8_t *h_rpt = nullptr;
+    uint32_t *h_red = nullptr;
     std::vector<uint32_t> head, tail;
+    std::vector<std::atomic<uint32_t>> cur_ed137;       // per channel: the word frames staged from now on carry
     std::vector<std::atomic_flag> slot_lock;
     std::atomic<uint32_t> hi_water{0};                 // 1 + highest channel ever staged
+    std::atomic<uint32_t> gate_mode{IGDSP_GATE_ALWAYS}; // igdsp_set_gate_mode: how a flush gates each frame's fold into the window
 
-    // flush: one pinned upload block + its device mirror (sections at 256-byte aligned offsets, one H2D copy), results
+    // flush: one pinned upload block + its device mirror (sections at 256-byte aligned offsets), per-channel device state and
+    // its published host snapshots.  igdsp_flush_begin snapshots + enqueues, igdsp_flush_end waits and publishes; the device
+    // writes each flush's {newest record, hold, probe} of every channel into the BACK set of pinned arrays, flush_end makes it
+    // the front set (pub_seq moves): igdsp_poll / get_hold / get_probe read the front set and never take flush_mu.
     uint8_t *h_up = nullptr, *d_up = nullptr;
     size_t up_bytes = 0;
-    igdsp_frame_stats *d_stats = nullptr;               // one record per staged frame of this flush
-    igdsp_frame_stats *h_fresh = nullptr;               // pinned: this flush's records
-    igdsp_frame_stats *h_stats = nullptr;               // pinned: last metered record per channel
+    igdsp_frame_stats *d_stats = nullptr;               // one record per staged frame of this flush (regions may have gaps, see flush_begin)
+    igdsp_frame_stats *d_last = nullptr;                // per channel: record of its newest metered frame
     igdsp_chan_hold *d_hold = nullptr;
-    igdsp_chan_hold *h_hold = nullptr;                  // pinned
-    std::vector<uint32_t> frames_seen, frames_dropped;  // per channel: frames metered / frames overwritten before a flush took them
-    std::vector<uint32_t> newest;                       // scratch of igdsp_flush: record index of a channel's newest frame
-    std::mutex flush_mu;
+    igdsp_chan_probe *d_probe = nullptr;
+    struct Published { igdsp_frame_stats *last; igdsp_chan_hold *hold; igdsp_chan_probe *probe; };
+    Published pub[2] = {};                              // pinned; pub[front] is what the poll entries read
+    std::atomic<uint32_t> front{0};
+    std::atomic<uint64_t> pub_seq{0};                   // moves whenever `front` does (readers retry when it moved under them)
+    std::vector<std::atomic<uint32_t>> frames_seen, frames_dropped;   // per channel: frames taken by a flush / overwritten before one took them
+    hipEvent_t flush_done = nullptr;
+    bool flush_open = false;                            // a flush_begin without its flush_end
+    uint32_t flush_nch = 0;                             // channels the open flush downloads
+    std::mutex flush_mu;                                // owner-thread entries (flush*, reset_hold)
+
+    // snapshot helpers: at many channels the flush's host-side snapshot (one pass over every channel's ring) is shared out to a
+    // few threads (igdsp_capi.hip: SnapshotPool)
+    struct SnapshotPool;
+    SnapshotPool *pool = nullptr;
 
     // device-wide work counters, ONE PAIR PER LAUNCH STREAM.  A persistent kernel draws its batches from the counter pair {next
     // batch, blocks done} it is handed and its last block re-arms the pair, so two kernels may share a pair only if they can never

@@ -270,6 +270,37 @@ __device__ __forceinline__ void wave_exit(igdsp_aggregate *agg, uint32_t rank, A
     }
 }
 
+// Merge one work item's window into hold[c] when several items share a channel (frame segments): device-scope integer
+// atomics (adds, and a CAS loop on the {peak_hold, level_max, level_min} word) — exact and order-independent, so the
+// result is bit-identical to the sequential fold (keeplogAudioLevel, Functions.cpp:2126-2145).
+__device__ __forceinline__ void hold_merge(igdsp_chan_hold *g, const igdsp_chan_hold &h)
+{
+    atomicAdd((unsigned long long *)&g->sumsq_acc, (unsigned long long)h.sumsq_acc);
+    atomicAdd(&g->count, h.count); atomicAdd(&g->level_sum, h.level_sum); atomicAdd(&g->samples, h.samples);
+    atomicAdd(&g->n_silent, h.n_silent); atomicAdd(&g->n_clipped, h.n_clipped);
+    uint32_t *pw = reinterpret_cast<uint32_t *>(&g->peak_hold);
+    uint32_t old = *pw, want;
+    do {
+        const uint32_t pk = max(old & 0xFFFFu, (uint32_t)h.peak_hold), mx = max((old >> 16) & 0xFFu, (uint32_t)h.level_max);
+        const uint32_t mn = min(old >> 24, (uint32_t)h.level_min);
+        want = pk | (mx << 16) | (mn << 24);
+        if (want == old) break;
+        const uint32_t seen = atomicCAS(pw, old, want);
+        if (seen == old) break;
+        old = seen;
+    } while (true);
+}
+
+// the same when ONE work item owns the channel for the whole launch: plain read-modify-write
+__device__ __forceinline__ void hold_add(igdsp_chan_hold *gp, const igdsp_chan_hold &h)
+{
+    igdsp_chan_hold g = *gp;
+    g.sumsq_acc += h.sumsq_acc; g.count += h.count; g.level_sum += h.level_sum; g.samples += h.samples;
+    g.peak_hold = max(g.peak_hold, h.peak_hold); g.level_max = max(g.level_max, h.level_max); g.level_min = min(g.level_min, h.level_min);
+    g.n_silent += h.n_silent; g.n_clipped += h.n_clipped;
+    *gp = g;
+}
+
 // ============================================================================
 // Shared machinery of the tuned n == 160 kernels (k_meter_chunk64, k_meter_rtp64, k_roundtrip_chunk64).
 //

@@ -25,6 +25,15 @@ struct LaunchCfg {
     bool out_spread = false;   // the launch's bulk output sits half in one, half in another memory class (igdsp_io_alloc)
 };
 
+// The ED-137 gated window of a fused packet launch (igdsp_decode_meter_window): hold / gate / work as in igdsp_window, work =
+// uint4[n_seg][C] run summaries or nullptr (no probe tracking); a unit = (one of n_groups = C / 64 channel groups, one of n_seg
+// segments of the F frames).
+struct WinArgs {
+    igdsp_chan_hold *hold = nullptr; const uint8_t *gate = nullptr; uint4 *work = nullptr;
+    uint32_t gate_mode = 0, alarm = IGDSP_PROBE_ALARM, n_seg = 1, n_groups = 0, F = 0;
+};
+constexpr uint32_t kWinMaxSeg = 8;                       // igdsp_window_work_bytes = kWinMaxSeg x C x 16
+
 hipError_t init_device_attributes();       // per-device kernel attributes; igdsp_create calls it with its device current
 hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant,
                                const uint8_t *payload, const uint8_t *codec, const uint16_t *len,
@@ -33,7 +42,12 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant,
                                igdsp_aggregate *agg, uint32_t rank, hipStream_t s);
 hipError_t launch_decode_meter_rtp(const LaunchCfg &cfg, const uint8_t *slots, const uint16_t *sizes, const uint8_t *codec, uint32_t C,
                                    uint32_t F, uint32_t stride, uint32_t hdr, igdsp_frame_stats *stats, igdsp_rtp_info *info,
-                                   igdsp_aggregate *agg, uint32_t rank, hipStream_t s, const uint8_t *radio = nullptr);
+                                   igdsp_aggregate *agg, uint32_t rank, hipStream_t s, const uint8_t *radio = nullptr, const WinArgs *win = nullptr);
+// window fold of records (per-frame ED-137 gates, silence run): igdsp_window_update; and the chaining of a fused launch's per-segment
+// run summaries into probe[c]
+hipError_t launch_window_update(const igdsp_frame_stats *stats, const igdsp_rtp_info *info, const uint16_t *len, uint32_t C, uint32_t F, uint32_t n,
+                                uint32_t gate_mode, uint32_t alarm, igdsp_chan_hold *hold, const uint8_t *gate, igdsp_chan_probe *probe, hipStream_t s);
+hipError_t launch_window_finish(const uint4 *work, uint32_t C, uint32_t n_seg, uint32_t alarm, igdsp_chan_probe *probe, hipStream_t s);
 hipError_t launch_diag_chunk32(const LaunchCfg &cfg, const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F,
                                igdsp_frame_stats *stats, uint64_t *diag, hipStream_t s);
 hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t *codec,
@@ -45,8 +59,9 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
                             igdsp_chan_hold *hold, const uint8_t *gate, int variant, hipStream_t s);
 hipError_t launch_hold_update(const igdsp_frame_stats *stats, const uint16_t *len, uint32_t C, uint32_t F, uint32_t n,
                               igdsp_chan_hold *hold, const uint8_t *gate, hipStream_t s);
-hipError_t launch_hold_fold_runs(const igdsp_frame_stats *stats, const uint16_t *len, uint32_t n, const uint32_t *runs, uint32_t n_runs,
-                                 igdsp_chan_hold *hold, hipStream_t s);
+hipError_t launch_flush_fold(const igdsp_frame_stats *stA, const igdsp_frame_stats *stB, const uint16_t *lenB, const uint2 *seq, const uint2 *runs,
+                             uint32_t n_channels, uint32_t gate_mode, uint32_t alarm, igdsp_chan_hold *hold, igdsp_chan_probe *probe,
+                             igdsp_frame_stats *last, hipStream_t s);
 hipError_t launch_hold_reset(igdsp_chan_hold *hold, uint32_t C, const uint8_t *mask, hipStream_t s);
 hipError_t launch_depayload(const LaunchCfg &cfg, const uint8_t *packets, const uint16_t *sizes, const uint8_t *radio,
                             uint32_t C, uint32_t F, uint32_t stride, uint32_t n, uint8_t *payload, uint16_t *len,

@@ -279,27 +279,6 @@ __global__ __launch_bounds__(256) void k_encode_scalar(const int16_t *__restrict
     }
 }
 
-// Merge one work item's window into hold[c] when several items share a channel (frame segments): device-scope integer
-// atomics (adds, and a CAS loop on the {peak_hold, level_max, level_min} word) — exact and order-independent, so the
-// result is bit-identical to the sequential fold (keeplogAudioLevel, Functions.cpp:2126-2145).
-__device__ __forceinline__ void hold_merge(igdsp_chan_hold *g, const igdsp_chan_hold &h)
-{
-    atomicAdd((unsigned long long *)&g->sumsq_acc, (unsigned long long)h.sumsq_acc);
-    atomicAdd(&g->count, h.count); atomicAdd(&g->level_sum, h.level_sum); atomicAdd(&g->samples, h.samples);
-    atomicAdd(&g->n_silent, h.n_silent); atomicAdd(&g->n_clipped, h.n_clipped);
-    uint32_t *pw = reinterpret_cast<uint32_t *>(&g->peak_hold);
-    uint32_t old = *pw, want;
-    do {
-        const uint32_t pk = max(old & 0xFFFFu, (uint32_t)h.peak_hold), mx = max((old >> 16) & 0xFFu, (uint32_t)h.level_max);
-        const uint32_t mn = min(old >> 24, (uint32_t)h.level_min);
-        want = pk | (mx << 16) | (mn << 24);
-        if (want == old) break;
-        const uint32_t seen = atomicCAS(pw, old, want);
-        if (seen == old) break;
-        old = seen;
-    } while (true);
-}
-
 // ============================================================================
 // Config #5 — fused decode -> stats -> re-encode -> per-channel hold (a1 + a2 + a5 + a6).
 // Channel-group-major: one wavefront owns 64 consecutive CHANNELS and walks all F frames of them
@@ -1014,22 +993,44 @@ __global__ __launch_bounds__(256) void k_hold_update(const igdsp_frame_stats *__
     hold[c] = h;
 }
 
-// a6 on the drop-in path: fold the records of one flush into hold[c].  The flush compacts every channel's staged frames
-// into consecutive records ("runs": {channel, first record, count}); one thread per run folds them in arrival order
-// (keeplogAudioLevel per frame, Functions.cpp:2126-2145).
-__global__ __launch_bounds__(256) void k_hold_fold_runs(const igdsp_frame_stats *__restrict__ stats, const uint16_t *__restrict__ len,
-                                                        uint32_t n, const uint32_t *__restrict__ runs, uint32_t n_runs,
-                                                        igdsp_chan_hold *__restrict__ hold)
+__device__ __forceinline__ bool frame_gate(uint32_t mode, uint32_t ed)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_runs) return;
-    const uint32_t c = runs[3 * r], first = runs[3 * r + 1], count = runs[3 * r + 2];
+    const uint32_t squ = (ed >> 28) & 1u, ptt = ed >> 29;
+    return mode == IGDSP_GATE_ALWAYS || (mode == IGDSP_GATE_SQU && squ != 0u) || (mode == IGDSP_GATE_PTT && ptt != 0u) ||
+           (mode == IGDSP_GATE_SQU_OR_PTT && (squ | ptt) != 0u);
+}
+
+// a6 on the drop-in path: fold the records of one flush into the per-channel state.  The flush hands every channel its staged
+// frames in ARRIVAL order — seq[first .. first + count) = {record id (group B: | 0x80000000), ED-137 word of the call when the
+// frame was staged}; one thread per channel folds them: keeplogAudioLevel per frame (Functions.cpp:2126-2145) under the frame
+// gate (PTT / SQU of the word, Functions.cpp:1136, 1160), the consecutive-silence run (adapter->rtpFalse,
+// TransportAdapter.cpp:657-673), and the channel's newest record for igdsp_poll.
+__global__ __launch_bounds__(256) void k_flush_fold(const igdsp_frame_stats *__restrict__ stA, const igdsp_frame_stats *__restrict__ stB,
+                                                    const uint16_t *__restrict__ lenB, const uint2 *__restrict__ seq, const uint2 *__restrict__ runs,
+                                                    uint32_t n_channels, uint32_t gate_mode, uint32_t alarm, igdsp_chan_hold *__restrict__ hold,
+                                                    igdsp_chan_probe *__restrict__ probe, igdsp_frame_stats *__restrict__ last)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_channels) return;
+    const uint2 run = runs[c];
+    if (run.y == 0u) return;
     igdsp_chan_hold h = hold[c];
-    for (uint32_t i = first; i < first + count; ++i) {
-        const igdsp_frame_stats s = stats[i];
+    igdsp_chan_probe p = probe[c];
+    igdsp_frame_stats newest = last[c];
+    for (uint32_t i = run.x; i < run.x + run.y; ++i) {
+        const uint2 e = seq[i];
+        const bool b = (e.x >> 31) != 0u;
+        const uint32_t id = e.x & 0x7FFFFFFFu;
+        const igdsp_frame_stats s = b ? stB[id] : stA[id];
         if (s.flags & IGDSP_FLAG_EMPTY) continue;
-        h.sumsq_acc += s.sumsq; h.count += 1u; h.level_sum += s.byte_mean;
-        h.samples += len ? min((uint32_t)len[i], n) : n;
+        const uint32_t l = b ? min((uint32_t)lenB[id], (uint32_t)IGDSP_MAX_PAYLOAD) : (uint32_t)IGDSP_SAMPLES_PER_FRAME;
+        newest = s;
+        if (l > 48u) {
+            if (s.flags & IGDSP_FLAG_PROBE_D5) { p.run += 1u; p.alarms += (p.run == alarm) ? 1u : 0u; }
+            else p.run = 0u;
+        }
+        if (!frame_gate(gate_mode, e.y)) continue;
+        h.sumsq_acc += s.sumsq; h.count += 1u; h.level_sum += s.byte_mean; h.samples += l;
         h.peak_hold = (uint16_t)max((uint32_t)h.peak_hold, (uint32_t)s.peak);
         h.level_max = (uint8_t)max((uint32_t)h.level_max, (uint32_t)s.byte_mean);
         h.level_min = (uint8_t)min((uint32_t)h.level_min, (uint32_t)s.byte_mean);
@@ -1037,6 +1038,8 @@ __global__ __launch_bounds__(256) void k_hold_fold_runs(const igdsp_frame_stats 
         h.n_clipped += (s.flags & IGDSP_FLAG_CLIPPED) ? 1u : 0u;
     }
     hold[c] = h;
+    probe[c] = p;
+    last[c] = newest;
 }
 
 __global__ __launch_bounds__(256) void k_hold_reset(igdsp_chan_hold *__restrict__ hold, uint32_t C,
@@ -1049,6 +1052,61 @@ __global__ __launch_bounds__(256) void k_hold_reset(igdsp_chan_hold *__restrict_
     h.sumsq_acc = 0; h.count = 0; h.level_sum = 0; h.samples = 0; h.peak_hold = 0;
     h.level_max = 0; h.level_min = 255; h.n_silent = 0; h.n_clipped = 0;
     hold[c] = h;
+}
+
+// ED-137 gated window over records (igdsp_window_update): one thread per channel walks its F frames in order — the generalisation
+// of k_hold_update to per-FRAME gates (ED-137 word of each frame's own packet: PTT type bits 31-29, SQU bit 28, masks
+// Functions.cpp:1136, 1160) plus the consecutive-silence run (adapter->rtpFalse, TransportAdapter.cpp:657-673).
+__global__ __launch_bounds__(256) void k_window_update(const igdsp_frame_stats *__restrict__ stats, const igdsp_rtp_info *__restrict__ info,
+                                                       const uint16_t *__restrict__ len, uint32_t C, uint32_t F, uint32_t n,
+                                                       uint32_t gate_mode, uint32_t alarm, igdsp_chan_hold *__restrict__ hold,
+                                                       const uint8_t *__restrict__ gate, igdsp_chan_probe *__restrict__ probe)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const bool open = gate == nullptr || gate[c] != 0;
+    igdsp_chan_hold h = hold[c];
+    igdsp_chan_probe p = probe ? probe[c] : igdsp_chan_probe{0u, 0u};
+    for (uint32_t f = 0; f < F; ++f) {
+        const uint64_t fi = (uint64_t)f * C + c;
+        const igdsp_frame_stats s = stats[fi];
+        if (s.flags & IGDSP_FLAG_EMPTY) continue;
+        uint32_t ed = 0, l = n;
+        if (info != nullptr) { const igdsp_rtp_info r = info[fi]; ed = r.ed137; l = r.payload_len; }
+        if (len != nullptr) l = len[fi];
+        l = min(l, n);
+        if (l > 48u) {
+            if (s.flags & IGDSP_FLAG_PROBE_D5) { p.run += 1u; p.alarms += (p.run == alarm) ? 1u : 0u; }
+            else p.run = 0u;
+        }
+        if (!open || !frame_gate(gate_mode, ed)) continue;
+        h.sumsq_acc += s.sumsq; h.count += 1u; h.level_sum += s.byte_mean; h.samples += l;
+        h.peak_hold = (uint16_t)max((uint32_t)h.peak_hold, (uint32_t)s.peak);
+        h.level_max = (uint8_t)max((uint32_t)h.level_max, (uint32_t)s.byte_mean);
+        h.level_min = (uint8_t)min((uint32_t)h.level_min, (uint32_t)s.byte_mean);
+        h.n_silent += (s.flags & IGDSP_FLAG_SILENT) ? 1u : 0u;
+        h.n_clipped += (s.flags & IGDSP_FLAG_CLIPPED) ? 1u : 0u;
+    }
+    hold[c] = h;
+    if (probe) probe[c] = p;
+}
+
+// Chain the per-segment run summaries of a fused window launch (k_meter_rtp64<WIN>) into probe[c], in segment order:
+// summary = {probe frames before the segment's first reset (all of them if it had none), run at its end, alarms after its first
+// reset, had a reset}.  The leading frames continue the incoming run and raise an alarm if they carry it across the alarm length.
+__global__ __launch_bounds__(256) void k_window_finish(const uint4 *__restrict__ work, uint32_t C, uint32_t n_seg, uint32_t alarm,
+                                                       igdsp_chan_probe *__restrict__ probe)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    igdsp_chan_probe p = probe[c];
+    for (uint32_t sg = 0; sg < n_seg; ++sg) {
+        const uint4 w = work[(uint64_t)sg * C + c];
+        if (p.run < alarm && p.run + w.x >= alarm) p.alarms += 1u;
+        p.run = w.w ? w.y : p.run + w.y;
+        p.alarms += w.z;
+    }
+    probe[c] = p;
 }
 
 hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t *codec, uint32_t C, uint32_t F,
@@ -1175,11 +1233,27 @@ hipError_t launch_hold_update(const igdsp_frame_stats *stats, const uint16_t *le
     return hipGetLastError();
 }
 
-hipError_t launch_hold_fold_runs(const igdsp_frame_stats *stats, const uint16_t *len, uint32_t n, const uint32_t *runs, uint32_t n_runs,
-                                 igdsp_chan_hold *hold, hipStream_t s)
+hipError_t launch_window_update(const igdsp_frame_stats *stats, const igdsp_rtp_info *info, const uint16_t *len, uint32_t C, uint32_t F, uint32_t n,
+                                uint32_t gate_mode, uint32_t alarm, igdsp_chan_hold *hold, const uint8_t *gate, igdsp_chan_probe *probe, hipStream_t s)
 {
-    if (n_runs == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_hold_fold_runs, dim3((n_runs + 255) / 256), dim3(256), 0, s, stats, len, n, runs, n_runs, hold);
+    if (C == 0 || F == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_window_update, dim3((C + 255) / 256), dim3(256), 0, s, stats, info, len, C, F, n, gate_mode, alarm, hold, gate, probe);
+    return hipGetLastError();
+}
+
+hipError_t launch_window_finish(const uint4 *work, uint32_t C, uint32_t n_seg, uint32_t alarm, igdsp_chan_probe *probe, hipStream_t s)
+{
+    if (C == 0 || n_seg == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_window_finish, dim3((C + 255) / 256), dim3(256), 0, s, work, C, n_seg, alarm, probe);
+    return hipGetLastError();
+}
+
+hipError_t launch_flush_fold(const igdsp_frame_stats *stA, const igdsp_frame_stats *stB, const uint16_t *lenB, const uint2 *seq, const uint2 *runs,
+                             uint32_t n_channels, uint32_t gate_mode, uint32_t alarm, igdsp_chan_hold *hold, igdsp_chan_probe *probe,
+                             igdsp_frame_stats *last, hipStream_t s)
+{
+    if (n_channels == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_flush_fold, dim3((n_channels + 255) / 256), dim3(256), 0, s, stA, stB, lenB, seq, runs, n_channels, gate_mode, alarm, hold, probe, last);
     return hipGetLastError();
 }
 

@@ -107,11 +107,23 @@ __device__ __forceinline__ void meter_short(const uint2 *lut, const uint32_t off
 // MIXED (packed form only): the header length is per channel, 20 bytes where radio[c] != 0 and 12 elsewhere (SIP and
 // ED-137 legs in one launch, as in the reference's process); `hdr` is then ignored.  The radio flags travel like the
 // codec ids: the frame lanes fetch them one item ahead and a ballot hands every piece its packet's bit.
-template <bool AGG, bool SLOT, bool MIXED = false>
+//
+// WIN (igdsp_decode_meter_window; C % 64 == 0): the ED-137 gated window in the same pass.  With C a multiple of 64, super-chunk
+// sidx = f * (C / 64) + g is frame f of channel group g, and lane l is channel 64 g + l in every one of them — so the kernel
+// only changes the ORDER in which a wave visits super-chunks: a work unit = (group g, segment of the F frames), walked in frame
+// order like k_roundtrip_lut64 walks its items, with the window (keeplogAudioLevel's count / sum / max / min, Functions.cpp:
+// 2126-2145, plus sum of squares, peak-hold, silent / clipped counts) and the consecutive-silence run (adapter->rtpFalse,
+// TransportAdapter.cpp:657-673) of each channel in the lane's registers.  The per-frame gate comes from the ED-137 word the frame
+// lane parses anyway (masks Functions.cpp:1136, 1160).  At a unit's last frame the window merges into hold[c] by integer
+// atomics (exact, order-free: bit-identical to the sequential fold; plain read-modify-write when there is one segment) and the
+// run leaves as a 16-byte summary {probe frames before the first reset, run at the end, alarms after the first reset, had a
+// reset} in work[seg][c], which k_window_finish chains in segment order.  The id stream of a wave carries the unit's segment
+// (bits 27-29) and a last-frame-of-unit flag (bit 31), so the load pipeline runs straight across unit boundaries.
+template <bool AGG, bool SLOT, bool MIXED = false, bool WIN = false>
 __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     const uint8_t *__restrict__ slots, const uint16_t *__restrict__ sizes, const uint8_t *__restrict__ codec, uint32_t C,
     uint32_t n_frames, uint32_t stride, uint32_t hdr, igdsp_frame_stats *__restrict__ stats, igdsp_rtp_info *__restrict__ info,
-    igdsp_aggregate *agg, uint32_t rank, uint32_t *gqueue, const uint8_t *__restrict__ radio = nullptr)
+    igdsp_aggregate *agg, uint32_t rank, uint32_t *gqueue, const uint8_t *__restrict__ radio = nullptr, const WinArgs win = WinArgs{})
 {
     static_assert(!(SLOT && MIXED), "slots always hold 20-byte headers");
     if (MIXED) hdr = 12u;
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     if (threadIdx.x == 0) { bq_init(bq, gqueue, gridDim.x, gb1); agg_block_init(aggb); }
     __syncthreads();
 
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint2 *strip = lds + kLutEntries + wave * kRtpStrip;
     const uint32_t off = (lane & 31u) * 8u;
     uint32_t pm[kRtpHalfLoads], fr[kRtpHalfLoads];        // fr = slot within the half | header-piece selector << 8 (shifts and v_bfe only look at the low 5 bits)
@@ -167,10 +179,38 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     auto ld = [&](const uint8_t *b, uint32_t o) { return SLOT ? ld_stream(reinterpret_cast<const uint4 *>(b + o)) : ld16_dw(b + o); };
     auto fetch_pt = [&](uint32_t sidx) { return (uint32_t)codec[(sidx * (uint32_t)kSuperFrames + lane) % C]; };
     const uint32_t n_batches = IGDSP_SPREAD_METER ? (n_super + (uint32_t)kRtpWaves - 1u) / (uint32_t)kRtpWaves : 0u;   // records only: no spreading
-    auto grab = [&]() { return bq_grab(bq, gqueue, G, lane, n_batches); };
+    // WIN: the wave's id stream = its units (round r: unit r * total_waves + wave * G + block, the roundtrip kernels' "a grid
+    // apart" order), each walked in frame order; wave-uniform state in SGPRs
+    uint32_t w_round = 0, w_g = 0, w_seg = 0, w_f = 0, w_fhi = 0;
+    auto grab = [&]() -> uint32_t {
+        if (!WIN) return bq_grab(bq, gqueue, G, lane, n_batches);
+        for (;;) {
+            if (w_f < w_fhi) {
+                const uint32_t id = (w_f * win.n_groups + w_g) | (w_seg << 27) | ((w_f + 1u == w_fhi) ? 0x80000000u : 0u);
+                ++w_f;
+                return id;
+            }
+            const uint64_t unit = (uint64_t)w_round * (G * (uint32_t)kRtpWaves) + (wave * G + blockIdx.x);
+            if (unit >= (uint64_t)win.n_groups * win.n_seg) return 0xFFFFFFFFu;
+            ++w_round;
+            w_seg = (uint32_t)(unit / win.n_groups);
+            w_g = (uint32_t)unit - w_seg * win.n_groups;
+            w_f = (uint32_t)(((uint64_t)win.F * w_seg) / win.n_seg);
+            w_fhi = (uint32_t)(((uint64_t)win.F * (w_seg + 1u)) / win.n_seg);
+        }
+    };
+    auto id_ok = [&](uint32_t id) { return WIN ? id != 0xFFFFFFFFu : id < n_super; };
+    auto id_sidx = [&](uint32_t id) { return WIN ? (id & 0x07FFFFFFu) : id; };
+    // the window of the unit under way (this lane = one channel): sum of squares, frames, byte-mean sum, samples,
+    // {peak_hold | level_max << 16}, level_min, {n_silent | n_clipped << 16}; the silence run {run so far, probe frames before the
+    // first reset | had-a-reset << 31, alarms after the first reset}
+    uint64_t w_sumsq = 0;
+    uint32_t w_cnt = 0, w_lsum = 0, w_samp = 0, w_pm = 0, w_min = 255u, w_sc = 0;
+    uint32_t r_trail = 0, r_lead = 0, r_hits = 0;
 
-    uint32_t sidx = spread_batch(blockIdx.x, n_batches) * (uint32_t)kRtpWaves + wave;     // batch blockIdx.x, slot = wave
-    if (sidx < n_super) {
+    uint32_t id_cur = WIN ? grab() : spread_batch(blockIdx.x, n_batches) * (uint32_t)kRtpWaves + wave;     // batch blockIdx.x, slot = wave
+    uint32_t sidx = id_sidx(id_cur);
+    if (id_ok(id_cur)) {
         uint4 X[kRtpHalfLoads], Y[kRtpHalfLoads];
         uint32_t cur_pt = fetch_pt(sidx);
         uint32_t cur_radio = fetch_radio(sidx);
@@ -192,8 +232,8 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
         }
         uint32_t s_next = grab();
         for (;;) {
-            const bool has_next = s_next < n_super;
-            const uint32_t s_load = has_next ? s_next : 0u;
+            const bool has_next = id_ok(s_next);
+            const uint32_t s_load = has_next ? id_sidx(s_next) : 0u;
             const uint32_t f0 = sidx * kSuperFrames;
             const bool my_alaw = cur_pt == IGDSP_PT_PCMA;
             const uint64_t amask = __ballot(my_alaw);
@@ -276,10 +316,49 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
                     u_sil += (uint32_t)__builtin_popcountll(__ballot(metered && (fl & IGDSP_FLAG_SILENT) != 0u));
                     u_clip += (uint32_t)__builtin_popcountll(__ballot(metered && (fl & IGDSP_FLAG_CLIPPED) != 0u));
                 }
+                if (WIN) {
+                    const uint32_t l = whole ? (uint32_t)kFrame : plen;
+                    // consecutive-silence run: only a metered frame that holds the probe bytes (payload length > 48) moves it
+                    if (metered && l > 48u) {
+                        if ((fl & IGDSP_FLAG_PROBE_D5) != 0u) {
+                            r_trail += 1u;
+                            r_hits += ((r_lead >> 31) != 0u && r_trail == win.alarm) ? 1u : 0u;
+                        } else {
+                            if ((r_lead >> 31) == 0u) r_lead = r_trail | 0x80000000u;
+                            r_trail = 0u;
+                        }
+                    }
+                    // frame gate from the ED-137 word of this frame's own packet (PTT type bits 31-29, SQU bit 28)
+                    const uint32_t squ = (ed >> 28) & 1u, ptt = ed >> 29;
+                    const bool g = win.gate_mode == IGDSP_GATE_ALWAYS || (win.gate_mode == IGDSP_GATE_SQU && squ != 0u) ||
+                                   (win.gate_mode == IGDSP_GATE_PTT && ptt != 0u) || (win.gate_mode == IGDSP_GATE_SQU_OR_PTT && (squ | ptt) != 0u);
+                    if (metered && g) {
+                        w_sumsq += s << 4; w_cnt += 1u; w_lsum += bm; w_samp += l;
+                        w_pm = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16_t, w_pm), __builtin_bit_cast(v2u16_t, peak | (bm << 16))));
+                        w_min = min(w_min, bm);
+                        w_sc += ((fl & IGDSP_FLAG_SILENT) ? 1u : 0u) + ((fl & IGDSP_FLAG_CLIPPED) ? 0x10000u : 0u);
+                    }
+                    if ((id_cur >> 31) != 0u) {             // wave-uniform: last frame of the unit
+                        const uint32_t cme = (sidx % win.n_groups) * (uint32_t)kSuperFrames + lane, seg = (id_cur >> 27) & 7u;
+                        if (w_cnt != 0u && (win.gate == nullptr || win.gate[cme] != 0)) {
+                            igdsp_chan_hold h;
+                            h.sumsq_acc = w_sumsq; h.count = w_cnt; h.level_sum = w_lsum; h.samples = w_samp;
+                            h.peak_hold = (uint16_t)(w_pm & 0xFFFFu); h.level_max = (uint8_t)(w_pm >> 16); h.level_min = (uint8_t)w_min;
+                            h.n_silent = w_sc & 0xFFFFu; h.n_clipped = w_sc >> 16;
+                            if (win.n_seg == 1u) hold_add(win.hold + cme, h);       // the wave owns hold[c]: plain read-modify-write
+                            else hold_merge(win.hold + cme, h);
+                        }
+                        if (win.work != nullptr)
+                            win.work[(uint64_t)seg * C + cme] = make_uint4((r_lead >> 31) ? (r_lead & 0x7FFFFFFFu) : r_trail, r_trail, r_hits, r_lead >> 31);
+                        w_sumsq = 0; w_cnt = 0; w_lsum = 0; w_samp = 0; w_pm = 0; w_min = 255u; w_sc = 0;
+                        r_trail = 0; r_lead = 0; r_hits = 0;
+                    }
+                }
             }
             wave_lds_fence();
             if (!has_next) break;
-            sidx = s_next;
+            id_cur = s_next;
+            sidx = id_sidx(s_next);
             s_next = s_after;
             cur_pt = nxt_pt;
             cur_radio = nxt_radio;
@@ -479,23 +558,38 @@ __global__ __launch_bounds__(256) void k_depayload_bytes(const uint8_t *__restri
 
 hipError_t launch_decode_meter_rtp(const LaunchCfg &cfg, const uint8_t *slots, const uint16_t *sizes, const uint8_t *codec, uint32_t C,
                                    uint32_t F, uint32_t stride, uint32_t hdr, igdsp_frame_stats *stats, igdsp_rtp_info *info,
-                                   igdsp_aggregate *agg, uint32_t rank, hipStream_t s, const uint8_t *radio)
+                                   igdsp_aggregate *agg, uint32_t rank, hipStream_t s, const uint8_t *radio, const WinArgs *win)
 {
     // stride == 0: the 192-byte slot format; otherwise packets packed at `stride` with a `hdr`-byte RTP header, or, with
-    // `radio`, a per-channel 20 / 12-byte header
+    // `radio`, a per-channel 20 / 12-byte header.  win: the gated window in the same pass (C % 64 == 0; launch_window_fused)
     const uint32_t n_frames = C * F;                       // caller guarantees a multiple of 64
     if (n_frames == 0) return hipSuccess;
-    const uint32_t grid = blocks_for(n_frames / kSuperFrames, kRtpWaves, (uint32_t)cfg.compute_units);
     const dim3 blk(kRtpWaves * 64);
+    if (win != nullptr) {
+        const uint32_t grid = blocks_for((uint64_t)win->n_groups * win->n_seg, kRtpWaves, (uint32_t)cfg.compute_units);
+        uint32_t *noq = nullptr;                           // units are assigned statically (a grid apart), no device queue
+        if (stride == 0) {
+            if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, true, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, noq, radio, *win);
+            else     hipLaunchKernelGGL((k_meter_rtp64<false, true, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, noq, radio, *win);
+        } else if (radio != nullptr) {
+            if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false, true, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, noq, radio, *win);
+            else     hipLaunchKernelGGL((k_meter_rtp64<false, false, true, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, noq, radio, *win);
+        } else {
+            if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, noq, radio, *win);
+            else     hipLaunchKernelGGL((k_meter_rtp64<false, false, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, noq, radio, *win);
+        }
+        return hipGetLastError();
+    }
+    const uint32_t grid = blocks_for(n_frames / kSuperFrames, kRtpWaves, (uint32_t)cfg.compute_units);
     if (stride == 0) {
-        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, cfg.gqueue, radio);
-        else     hipLaunchKernelGGL((k_meter_rtp64<false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, cfg.gqueue, radio);
+        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, cfg.gqueue, radio, WinArgs{});
+        else     hipLaunchKernelGGL((k_meter_rtp64<false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, cfg.gqueue, radio, WinArgs{});
     } else if (radio != nullptr) {
-        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, cfg.gqueue, radio);
-        else     hipLaunchKernelGGL((k_meter_rtp64<false, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, cfg.gqueue, radio);
+        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, cfg.gqueue, radio, WinArgs{});
+        else     hipLaunchKernelGGL((k_meter_rtp64<false, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, cfg.gqueue, radio, WinArgs{});
     } else {
-        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, cfg.gqueue, radio);
-        else     hipLaunchKernelGGL((k_meter_rtp64<false, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, cfg.gqueue, radio);
+        if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, cfg.gqueue, radio, WinArgs{});
+        else     hipLaunchKernelGGL((k_meter_rtp64<false, false>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, cfg.gqueue, radio, WinArgs{});
     }
     return hipGetLastError();
 }

@@ -29,8 +29,10 @@ extern "C" {
 #endif
 
 /* 2: igdsp_io_alloc / igdsp_io_free, igdsp_wav_expand, staging ring (igdsp_level.dropped, IGDSP_STAGE_DEPTH); every round-1 entry is
- * unchanged in signature and meaning. */
-#define IGDSP_ABI_VERSION 2
+ * unchanged in signature and meaning.
+ * 3: additive again — the ED-137 gated window (igdsp_window, igdsp_decode_meter_window, igdsp_window_update, igdsp_chan_probe),
+ * igdsp_set_ed137 / igdsp_set_gate_mode / igdsp_get_probe on the single-frame path, igdsp_flush_begin / igdsp_flush_end. */
+#define IGDSP_ABI_VERSION 3
 
 /* ---- error codes (0 == PJ_SUCCESS-style success) ------------------------- */
 #define IGDSP_OK          0
@@ -197,6 +199,26 @@ int igdsp_on_rtp_frame(igdsp_ctx *ctx, int32_t call_id, uint8_t pt,
  * staged frames processed. */
 int igdsp_flush(igdsp_ctx *ctx, uint32_t *n_frames_out);
 
+/* Non-blocking form of igdsp_flush, for owner threads that must not wait (the reference's hook and its 40 ms timer slot never
+ * wait: TransportAdapter.cpp:303, roip_ed137.cpp:1756).  igdsp_flush_begin snapshots the staged frames, enqueues upload, kernels
+ * and downloads on the context's stream and returns; igdsp_flush_end waits for that work (normally finished long before the next
+ * tick) and publishes the levels for igdsp_poll.  wait == 0: return IGDSP_EBUSY instead of waiting if the device has not finished.
+ * igdsp_flush == begin + end(wait = 1).  A begin while the previous flush is still open ends it first (waiting).  igdsp_poll /
+ * igdsp_get_hold / igdsp_get_probe read the PUBLISHED snapshot and never wait for a flush in flight. */
+int igdsp_flush_begin(igdsp_ctx *ctx, uint32_t *n_frames_out);
+int igdsp_flush_end(igdsp_ctx *ctx, int wait);
+
+/* The third hook of the reference's boundary, setIncomingED137Value(uint32_t value, pjsua_acc_id) (roip_ed137.h:273; called by
+ * transport_rtp_cb with ntohl(adapter->ed137_value), TransportAdapter.cpp:305,313): records the call's current ED-137 word (host
+ * order).  Frames staged by igdsp_on_rtp_frame AFTER it carry that word, and igdsp_flush folds a frame into the call's window only
+ * if the word passes the context's gate mode (igdsp_set_gate_mode: IGDSP_GATE_* below; default IGDSP_GATE_ALWAYS = every frame,
+ * the round-2 behaviour).  Wait-free for the caller, like igdsp_on_rtp_frame.  igdsp_get_probe: the call's consecutive-silence
+ * state (adapter->rtpFalse, TransportAdapter.cpp:657-673) as of the last finished flush. */
+int igdsp_set_ed137(igdsp_ctx *ctx, int32_t call_id, uint32_t ed137_value);
+int igdsp_set_gate_mode(igdsp_ctx *ctx, uint32_t gate_mode);
+struct igdsp_chan_probe;
+int igdsp_get_probe(igdsp_ctx *ctx, uint32_t channel, struct igdsp_chan_probe *out);
+
 /* (iii) results poll for one channel (valid after a flush). */
 int igdsp_poll(igdsp_ctx *ctx, uint32_t channel, igdsp_level *out);
 int igdsp_poll_call(igdsp_ctx *ctx, int32_t call_id, igdsp_level *out);
@@ -317,6 +339,63 @@ int igdsp_decode_meter_packets_mixed(igdsp_ctx *ctx, const uint8_t *d_packets, c
                                      const uint8_t *d_radio, uint32_t n_channels, uint32_t n_frames, uint32_t pkt_stride,
                                      igdsp_frame_stats *d_stats, igdsp_rtp_info *d_info,
                                      igdsp_aggregate *d_agg, uint32_t rank, void *stream);
+
+/* ---- SURVEY 8(f) rank 1, last clause: squelch / PTT gating of the meter from the ED-137 word, on the device ---------------------
+ * The reference folds a frame's level into the PTT window (keeplogAudioLevel, Functions.cpp:2126-2145) while the window is open,
+ * and reads PTT / squelch out of the ED-137 word of the RTP header extension (masks: PTT type Functions.cpp:1136, PTT id :1148,
+ * SQU :1160, BSS :1018).  A window here is the per-channel igdsp_chan_hold; a metered frame (f, c) is folded into hold[c] iff
+ *     (d_gate == NULL || d_gate[c] != 0)                     the caller's per-channel window state (eventPttSQL_In_LoggingOn)
+ *  && frame_gate(gate_mode, ED-137 word of the frame's OWN packet)
+ * with frame_gate = 1 (ALWAYS), SQU bit set (SQU), PTT type != 0 (PTT), either (SQU_OR_PTT).  Legs without an ED-137 word
+ * (12-byte RTP header: the word reads 0, as get_ed137_value gives it) are therefore never folded under SQU / PTT gating.
+ * Independently of the gate, d_probe[c] follows the reference's consecutive-silence counter (adapter->rtpFalse,
+ * TransportAdapter.cpp:657-673): a metered frame long enough to hold the probe bytes (payload length > 48) adds 1 to `run` when
+ * its IGDSP_FLAG_PROBE_D5 is set and clears `run` when it is not; shorter / empty frames leave it; `alarms` counts how often
+ * `run` reached probe_alarm (the reference logs at exactly 500).  Frames of a channel are taken in frame order f = 0 .. F-1. */
+#define IGDSP_GATE_ALWAYS      0u
+#define IGDSP_GATE_SQU         1u
+#define IGDSP_GATE_PTT         2u
+#define IGDSP_GATE_SQU_OR_PTT  3u
+#define IGDSP_PROBE_ALARM    500u   /* TransportAdapter.cpp:666 */
+typedef struct igdsp_chan_probe {
+    uint32_t run;        /* consecutive probe-matching frames up to now (adapter->rtpFalse)   */
+    uint32_t alarms;     /* times run reached the alarm length                                 */
+} igdsp_chan_probe;
+typedef struct igdsp_window {
+    uint32_t gate_mode;           /* IGDSP_GATE_*                                                                    */
+    uint32_t probe_alarm;         /* 0 = IGDSP_PROBE_ALARM                                                           */
+    igdsp_chan_hold *d_hold;      /* [C] window aggregate the gated frames are folded into (required)                */
+    const uint8_t *d_gate;        /* [C] optional per-channel window state, 0 = closed                               */
+    igdsp_chan_probe *d_probe;    /* [C] optional consecutive-silence state                                          */
+    void *d_work;                 /* igdsp_window_work_bytes(C) bytes of device scratch, 16-byte aligned: required by */
+                                  /* igdsp_decode_meter_window when d_probe is given (per-segment run summaries);    */
+                                  /* not used by igdsp_window_update.  One buffer per stream that launches            */
+} igdsp_window;
+size_t igdsp_window_work_bytes(uint32_t n_channels);
+
+/* Fold records into the window: the generalisation of igdsp_hold_update to per-FRAME gates.  d_info (optional) = the
+ * igdsp_rtp_info[F][C] of igdsp_depayload / the fused packet entries: supplies each frame's ED-137 word (NULL: word 0) and,
+ * when d_len is NULL, its length (payload_len clamped to samples_per_frame; NULL as well: samples_per_frame).  EMPTY records
+ * are skipped.  One thread per channel walks its F frames in order. */
+int igdsp_window_update(igdsp_ctx *ctx, const igdsp_frame_stats *d_stats, const igdsp_rtp_info *d_info, const uint16_t *d_len,
+                        uint32_t n_channels, uint32_t n_frames, uint32_t samples_per_frame, const igdsp_window *win, void *stream);
+
+/* The fused packet entries with the window folded in the SAME launch: packets -> records (+ info, aggregate) -> hold[c] and
+ * probe[c], one pass over the packets.  layout selects the packet format and which of the arguments apply:
+ *   IGDSP_PKT_SLOTS  = igdsp_decode_meter_rtp            (192-byte slots; d_sizes, d_radio, pkt_stride, hdr_bytes ignored)
+ *   IGDSP_PKT_PACKED = igdsp_decode_meter_packets        (pkt_stride, hdr_bytes 12 / 20, optional d_sizes; d_radio ignored)
+ *   IGDSP_PKT_MIXED  = igdsp_decode_meter_packets_mixed  (pkt_stride, d_radio, optional d_sizes; hdr_bytes ignored)
+ * Same argument rules and records as those entries.  With n_channels % 64 == 0 the kernel walks channel groups (a wavefront
+ * keeps 64 channels' windows in registers over a segment of the frames and merges them with integer atomics: exact and
+ * order-free, bit-identical to the sequential fold); other channel counts run the plain fused kernel followed by
+ * igdsp_window_update on the same stream; d_info has to be given then (it carries each frame's ED-137 word and length). */
+#define IGDSP_PKT_SLOTS   0u
+#define IGDSP_PKT_PACKED  1u
+#define IGDSP_PKT_MIXED   2u
+int igdsp_decode_meter_window(igdsp_ctx *ctx, uint32_t layout, const uint8_t *d_packets, const uint16_t *d_sizes,
+                              const uint8_t *d_codec, const uint8_t *d_radio, uint32_t n_channels, uint32_t n_frames,
+                              uint32_t pkt_stride, uint32_t hdr_bytes, igdsp_frame_stats *d_stats, igdsp_rtp_info *d_info,
+                              igdsp_aggregate *d_agg, uint32_t rank, const igdsp_window *win, void *stream);
 
 /* ---- recorder-compatible output on the device (WavWriter.cpp:63-156) ------------------------------
  * The step AFTER the path.  For every channel c of a batch payload[F][C][n] one complete file image exactly as the

@@ -239,6 +239,52 @@ void orc_roundtrip_peakhold(const uint8_t *payload, const uint8_t *codec, uint32
 }
 
 /* ------------------------------------------------------------------------- */
+/* ED-137 gated window + consecutive-silence run (see igdsp_oracle.h)           */
+/* ------------------------------------------------------------------------- */
+static int orc_frame_gate(uint32_t mode, uint32_t ed137)
+{
+    const uint32_t ptt = (ed137 & 0xe0000000u) >> 29;      /* Functions.cpp:1136 */
+    const uint32_t squ = (ed137 & 0x10000000u) >> 28;      /* Functions.cpp:1160 */
+    switch (mode) {
+    case 0: return 1;
+    case 1: return squ != 0;
+    case 2: return ptt != 0;
+    default: return squ != 0 || ptt != 0;
+    }
+}
+
+void orc_window_update(const orc_frame_stats *stats, const orc_rtp_info *info, const uint16_t *len,
+                       uint32_t C, uint32_t F, uint32_t n, uint32_t gate_mode, uint32_t alarm,
+                       orc_chan_hold *hold, const uint8_t *gate, orc_chan_probe *probe)
+{
+    if (alarm == 0) alarm = 500;                          /* TransportAdapter.cpp:666 */
+    for (uint32_t f = 0; f < F; ++f)
+        for (uint32_t c = 0; c < C; ++c) {
+            const size_t fi = (size_t)f * C + c;
+            const orc_frame_stats *s = &stats[fi];
+            if (s->flags & 0x08) continue;                /* EMPTY: not metered, touches nothing */
+            uint32_t l = len ? len[fi] : (info ? info[fi].payload_len : n);
+            if (l > n) l = n;
+            if (probe && l > 48) {                        /* TransportAdapter.cpp:657-673 */
+                if (s->flags & 0x02) { if (++probe[c].run == alarm) probe[c].alarms += 1; }
+                else probe[c].run = 0;
+            }
+            if (gate && !gate[c]) continue;
+            if (!orc_frame_gate(gate_mode, info ? info[fi].ed137 : 0u)) continue;
+            orc_chan_hold *h = &hold[c];                  /* keeplogAudioLevel, Functions.cpp:2126-2145 */
+            h->count += 1;
+            h->level_sum += s->byte_mean;
+            h->samples += l;
+            h->sumsq_acc += s->sumsq;
+            if (s->peak > h->peak_hold) h->peak_hold = s->peak;
+            if (s->byte_mean > h->level_max) h->level_max = s->byte_mean;
+            if (s->byte_mean < h->level_min) h->level_min = s->byte_mean;
+            h->n_silent += (s->flags & 1) ? 1 : 0;
+            h->n_clipped += (s->flags & 4) ? 1 : 0;
+        }
+}
+
+/* ------------------------------------------------------------------------- */
 /* changeUplinkOrder (roip_ed137.cpp:6379-6499).  The reference fills packed   */
 /* bit-field structs (GCC allocates fields from the least significant bit) and */
 /* memcpy()s them out; here every output byte is written as the OR of its      */

@@ -74,6 +74,19 @@ typedef struct { uint32_t ed137; uint16_t payload_len; uint8_t pt; uint8_t flags
 void orc_depayload(const uint8_t *packets, const uint16_t *sizes, const uint8_t *radio, uint32_t C, uint32_t F,
                    uint32_t stride, uint32_t n, uint8_t *payload, uint16_t *len, orc_rtp_info *info);
 
+/* The ED-137 gated window (last clause), restated from the reference's own pieces:
+ *   window fold      keeplogAudioLevel, Functions.cpp:2126-2145 (count / sum / max / min while the window is open)
+ *   gate bits        get_IPRadioPttStatus  (ed137 & 0xe0000000) >> 29, Functions.cpp:1136;
+ *                    get_IPRadioSquelch    (ed137 & 0x10000000) >> 28, Functions.cpp:1160
+ *   silence run      adapter->rtpFalse, TransportAdapter.cpp:657-673: += 1 when bytes 40 / 50 / 60 of the TX packet are 0xD5
+ *                    (payload bytes 28 / 38 / 48 = IGDSP_FLAG_PROBE_D5), = 0 when they are not, untouched when the packet is
+ *                    too short to hold them (size > 60 <=> payload length > 48); "alarm" when it reaches exactly 500
+ * gate_mode 0 always, 1 SQU, 2 PTT type != 0, 3 either.  info nullable (ED-137 word 0; length from len or n); len nullable. */
+typedef struct { uint32_t run, alarms; } orc_chan_probe;
+void orc_window_update(const orc_frame_stats *stats, const orc_rtp_info *info, const uint16_t *len,
+                       uint32_t C, uint32_t F, uint32_t n, uint32_t gate_mode, uint32_t alarm,
+                       orc_chan_hold *hold, const uint8_t *gate, orc_chan_probe *probe /*nullable*/);
+
 /* roip_ed137.cpp:6379-6499 changeUplinkOrder restated (unsigned-char target, GCC LSB-first bit-fields) */
 void orc_g726_reorder(const uint8_t *in, uint8_t *out, size_t n, int mode);
 

@@ -43,6 +43,8 @@ assert FRAME_STATS.itemsize == 16 and CHAN_HOLD.itemsize == 32 and AGGREGATE.ite
 
 RTP_INFO = np.dtype([("ed137", "<u4"), ("payload_len", "<u2"), ("pt", "u1"), ("flags", "u1")], align=True)
 assert RTP_INFO.itemsize == 8
+CHAN_PROBE = np.dtype([("run", "<u4"), ("alarms", "<u4")], align=True)
+GATE_ALWAYS, GATE_SQU, GATE_PTT, GATE_SQU_OR_PTT = 0, 1, 2, 3
 FLAG_SILENT, FLAG_PROBE_D5, FLAG_CLIPPED, FLAG_EMPTY = 1, 2, 4, 8
 ENC_SUN16, ENC_G191 = 0, 1
 SEED = 0x20241218
@@ -89,6 +91,8 @@ def lib() -> C.CDLL:
         L.orc_hold_reset.restype = None; L.orc_hold_reset.argtypes = [vp, C.c_uint32, vp]
         L.orc_hold_update.restype = None
         L.orc_hold_update.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+        L.orc_window_update.restype = None
+        L.orc_window_update.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
         L.orc_roundtrip_peakhold.restype = None
         L.orc_roundtrip_peakhold.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_int]
         L.orc_depayload.restype = None
@@ -185,6 +189,21 @@ def hold_update(stats, n, hold, gate=None):
         gate = np.ascontiguousarray(gate, dtype=np.uint8)
     lib().orc_hold_update(_p(np.ascontiguousarray(stats)), C_, F_, n, _p(hold), _p(gate))
     return hold
+
+
+def window_update(stats, hold, info=None, length=None, n=160, gate_mode=GATE_ALWAYS, alarm=0, gate=None, probe=None):
+    """Fold stats[F][C] into hold[C] under per-frame ED-137 gates, and follow the consecutive-silence run in probe[C]
+    (orc_window_update, oracle/igdsp_oracle.h).  hold / probe are updated in place and returned."""
+    stats = np.ascontiguousarray(stats)
+    F_, C_ = stats.shape
+    if info is not None:
+        info = np.ascontiguousarray(info, dtype=RTP_INFO)
+    if length is not None:
+        length = np.ascontiguousarray(length, dtype="<u2")
+    if gate is not None:
+        gate = np.ascontiguousarray(gate, dtype=np.uint8)
+    lib().orc_window_update(_p(stats), _p(info), _p(length), C_, F_, n, gate_mode, alarm, _p(hold), _p(gate), _p(probe))
+    return hold, probe
 
 
 def roundtrip_peakhold(payload, codec, hold, gate=None, variant=ENC_G191):

@@ -29,7 +29,7 @@ def test_header_symbols_all_exported_and_bound(lib):
     raw = ctypes.CDLL(capi.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.igdsp_abi_version() == capi.ABI_VERSION == 2
+    assert lib.igdsp_abi_version() == capi.ABI_VERSION == 3
 
 
 def test_struct_layouts_agree(orc):
@@ -37,6 +37,10 @@ def test_struct_layouts_agree(orc):
     assert capi.CHAN_HOLD.itemsize == orc.CHAN_HOLD.itemsize == 32
     assert capi.AGGREGATE.itemsize == orc.AGGREGATE.itemsize == 8 * capi.AGG_WORDS == 896
     assert ctypes.sizeof(capi.Level) == 20
+    # ABI 3: the gated window
+    assert capi.CHAN_PROBE.itemsize == orc.CHAN_PROBE.itemsize == ctypes.sizeof(capi.ChanProbe) == 8
+    assert ctypes.sizeof(capi.Window) == 8 + 4 * ctypes.sizeof(ctypes.c_void_p) == 40
+    assert (capi.GATE_ALWAYS, capi.GATE_SQU, capi.GATE_PTT, capi.GATE_SQU_OR_PTT) == (orc.GATE_ALWAYS, orc.GATE_SQU, orc.GATE_PTT, orc.GATE_SQU_OR_PTT) == (0, 1, 2, 3)
     for a, b in ((capi.FRAME_STATS, orc.FRAME_STATS), (capi.CHAN_HOLD, orc.CHAN_HOLD), (capi.AGGREGATE, orc.AGGREGATE)):
         assert a.names == b.names
         assert [a.fields[n][1] for n in a.names] == [b.fields[n][1] for n in b.names]
@@ -44,7 +48,8 @@ def test_struct_layouts_agree(orc):
     hdr = open(os.path.join(ROOT, "include", "igdsp.h")).read()
     for name, val in (("IGDSP_PT_PCMU", capi.PT_PCMU), ("IGDSP_PT_PCMA", capi.PT_PCMA), ("IGDSP_PT_R2S", capi.PT_R2S),
                       ("IGDSP_SAMPLES_PER_FRAME", capi.SAMPLES_PER_FRAME), ("IGDSP_MAX_PAYLOAD", capi.MAX_PAYLOAD),
-                      ("IGDSP_AGG_MAX_RANKS", capi.AGG_MAX_RANKS)):
+                      ("IGDSP_AGG_MAX_RANKS", capi.AGG_MAX_RANKS), ("IGDSP_PROBE_ALARM", capi.PROBE_ALARM), ("IGDSP_PKT_MIXED", capi.PKT_MIXED),
+                      ("IGDSP_GATE_SQU_OR_PTT", capi.GATE_SQU_OR_PTT), ("IGDSP_ABI_VERSION", capi.ABI_VERSION)):
         m = re.search(rf"#define\s+{name}\s+(\d+)", hdr)
         assert m and int(m.group(1)) == val, name
 

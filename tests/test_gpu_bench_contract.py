@@ -55,7 +55,7 @@ def test_bench_json_contract_small(orc):
     assert abs(d["aggregate"]["node_rms"] - float(np.sqrt(int(agg["sumsq"]) / int(agg["samples"])))) < 1e-3
 
 
-@pytest.mark.parametrize("mode", ["store", "roundtrip", "rtp", "packets", "depayload", "encode"])
+@pytest.mark.parametrize("mode", ["store", "roundtrip", "rtp", "packets", "window", "depayload", "encode"])
 def test_bench_secondary_modes_run(mode):
     d = _run(["--channels", "1024", "--frames", "16", "--mode", mode, "--no-cpu-baseline"])
     assert d["value"] > 0 and d["roofline"]["achieved"] > 0 and d["cpu_baseline"] is None

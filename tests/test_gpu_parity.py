@@ -963,3 +963,65 @@ def test_io_alloc_places_buffers_and_they_work(ctx, orc):
     assert ctx.L.igdsp_io_alloc(ctx.h, arr, 1, 0, C.byref(st_), C.byref(r_)) == -22
     assert ctx.L.igdsp_io_alloc(ctx.h, arr, 0, 0, C.byref(st_), C.byref(r_)) == -22
     assert ctx.L.igdsp_io_free(ctx.h, None) == 0
+
+
+def test_flush_gates_by_ed137_word_and_follows_the_silence_run(orc):
+    """The drop-in path with the reference's third hook: igdsp_set_ed137 (= setIncomingED137Value, roip_ed137.h:273) gives a call
+    its current ED-137 word, igdsp_set_gate_mode picks the gate, and every flush folds each staged frame into the call's window
+    only if the word it was staged under passes (PTT / SQU masks Functions.cpp:1136, 1160); the consecutive-silence run
+    (adapter->rtpFalse, TransportAdapter.cpp:657-673) follows EVERY frame in arrival order — also when 160-byte and other frames
+    of one call alternate inside a flush.  Against the oracle's window restatement over all frames; begin / end split; poll
+    while a flush is open."""
+    nch = 70
+    c = capi.Context(device=0, max_channels=nch)
+    try:
+        for ch in range(nch):
+            c.map_call(500 + ch, ch)
+        rng = np.random.default_rng(5)
+        for mode in (capi.GATE_SQU, capi.GATE_PTT, capi.GATE_SQU_OR_PTT, capi.GATE_ALWAYS):
+            c.set_gate_mode(mode)
+            c.reset_hold()
+            hold = orc.hold_new(nch)
+            probe = np.zeros(nch, orc.CHAN_PROBE)
+            for ch in range(nch):
+                p = c.get_probe(ch)
+                probe["run"][ch], probe["alarms"][ch] = p.run, p.alarms          # the run carries over from the previous mode's frames
+            last = {}
+            for tick in range(9):
+                staged = 0
+                for ch in range(nch):
+                    for j in range(int(rng.integers(0, 4))):
+                        if rng.integers(0, 3) == 0:
+                            word = int(rng.integers(0, 1 << 32)) if rng.integers(0, 2) else 0
+                            c.set_ed137(500 + ch, word)
+                            last[("w", ch)] = word
+                        word = last.get(("w", ch), 0)
+                        ln = 160 if rng.integers(0, 4) else int(rng.choice([24, 48, 52, 164, 255]))
+                        pl = np.full(ln, 0xD5, np.uint8) if rng.integers(0, 2) else orc.gen_uniform(ln, seed=tick * 100000 + ch * 10 + j)
+                        assert c.on_rtp_frame(500 + ch, 8, pl.tobytes()) == 0
+                        est = orc.decode_meter(pl.reshape(1, 1, -1), [8])
+                        info = np.zeros((1, 1), orc.RTP_INFO)
+                        info["ed137"], info["payload_len"] = word, ln
+                        orc.window_update(est, hold[ch:ch + 1], info=info, n=256, gate_mode=mode, probe=probe[ch:ch + 1])
+                        last[ch] = est
+                        staged += 1
+                if tick % 2:
+                    assert c.flush() == staged
+                else:                                                    # the non-blocking pair, with a poll in between
+                    assert c.flush_begin() == staged
+                    c.poll(0)
+                    assert c.flush_end(wait=True) == 0
+                for ch in range(nch):
+                    if ch in last:
+                        lv = c.poll(ch)
+                        assert (lv.byte_mean, lv.peak, lv.flags) == (int(last[ch]["byte_mean"][0, 0]), int(last[ch]["peak"][0, 0]), int(last[ch]["flags"][0, 0]))
+            for ch in range(nch):
+                h, p = c.get_hold(ch), c.get_probe(ch)
+                for f in capi.CHAN_HOLD.names:
+                    assert int(h[f]) == int(hold[f][ch]), (mode, f, ch)
+                assert (p.run, p.alarms) == (int(probe["run"][ch]), int(probe["alarms"][ch])), (mode, ch)
+            if mode != capi.GATE_ALWAYS:
+                assert 0 < int(hold["count"].sum()) < int(sum(c.poll(ch).frames for ch in range(nch)))
+        assert c.L.igdsp_set_gate_mode(c.h, 9) == -22 and c.L.igdsp_set_ed137(c.h, 9999, 0) == -2
+    finally:
+        c.close()

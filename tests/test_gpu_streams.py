@@ -89,6 +89,7 @@ def test_unsynchronised_launches_on_two_streams_and_two_threads(orc):
     ctx.decode_meter(d_big, d_bcd, Cb, Fb, 160, st_ref, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     st_blk = [gu.dev_zeros(Fb * Cb * 16, 0xEE) for _ in streams]
+    torch.cuda.synchronize()                            # every fill ran on torch's stream: done before the other streams write
 
     # the drop-in path rides along on the context's own stream: 200 calls, frames staged and flushed while the two threads enqueue
     nch = 200

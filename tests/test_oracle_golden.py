@@ -207,3 +207,51 @@ def test_hold_semantics_follow_ptt_logger(orc):
     assert h["level_sum"][0] == 300 * 255 and (int(h["level_sum"][0]) & 0xFFFF) == (300 * 255) % 65536
     assert h["level_max"].tolist() == [255, 0, 255] and h["level_min"].tolist() == [255, 255, 255]
     assert h["peak_hold"][0] == 0 and h["peak_hold"][2] == orc.decode_table(8)[0xFF]
+
+
+def test_window_restatement_against_plain_python(orc):
+    """orc_window_update (the C restatement of the ED-137 gated window: keeplogAudioLevel Functions.cpp:2126-2145 under the
+    PTT / SQU bits of Functions.cpp:1136 / 1160, and the consecutive-silence run of TransportAdapter.cpp:657-673) against a
+    second, plain-Python statement of the same rules — every gate mode, closed channel gates, EMPTY records, short frames that
+    leave the run alone, an alarm length small enough to fire.  The reference holds no vector for this; the ED-137 masks are pinned
+    to its source text."""
+    rng = np.random.default_rng(1)
+    F_, C_, n = 40, 7, 160
+    pl = orc.gen_uniform(F_ * C_ * n).reshape(F_, C_, n).copy()
+    pl[rng.random((F_, C_)) < 0.5] = 0xD5
+    st = orc.decode_meter(pl, np.full(C_, 8, np.uint8))
+    info = np.zeros((F_, C_), orc.RTP_INFO)
+    info["ed137"] = rng.integers(0, 2 ** 32, size=(F_, C_), dtype=np.uint64).astype(np.uint32)
+    info["payload_len"] = np.where(rng.random((F_, C_)) < 0.2, 40, 160)
+    st["flags"][rng.random((F_, C_)) < 0.1] |= orc.FLAG_EMPTY
+    gate = (np.arange(C_) % 3 != 0).astype(np.uint8)
+    for mode in range(4):
+        hold, probe = orc.hold_new(C_), np.zeros(C_, orc.CHAN_PROBE)
+        orc.window_update(st, hold, info=info, gate_mode=mode, alarm=3, gate=gate, probe=probe)
+        for c in range(C_):
+            run = al = cnt = lsum = smp = ss = pk = mx = ns = nc = 0
+            mn = 255
+            for f in range(F_):
+                s = st[f, c]
+                if s["flags"] & orc.FLAG_EMPTY:
+                    continue
+                l = min(int(info["payload_len"][f, c]), n)
+                if l > 48:
+                    if s["flags"] & orc.FLAG_PROBE_D5:
+                        run += 1
+                        al += run == 3
+                    else:
+                        run = 0
+                ed = int(info["ed137"][f, c])
+                squ, ptt = (ed & 0x10000000) >> 28, (ed & 0xe0000000) >> 29           # Functions.cpp:1160, 1136
+                g = {0: 1, 1: squ, 2: int(ptt != 0), 3: int(squ or ptt != 0)}[mode]
+                if not gate[c] or not g:
+                    continue
+                cnt += 1; lsum += int(s["byte_mean"]); smp += l; ss += int(s["sumsq"]); pk = max(pk, int(s["peak"]))
+                mx = max(mx, int(s["byte_mean"])); mn = min(mn, int(s["byte_mean"]))
+                ns += bool(s["flags"] & orc.FLAG_SILENT); nc += bool(s["flags"] & orc.FLAG_CLIPPED)
+            h = hold[c]
+            got = tuple(int(h[k]) for k in ("count", "level_sum", "samples", "sumsq_acc", "peak_hold", "level_max", "level_min", "n_silent", "n_clipped"))
+            assert got == (cnt, lsum, smp, ss, pk, mx, mn, ns, nc), (mode, c)
+            assert (int(probe["run"][c]), int(probe["alarms"][c])) == (run, al), (mode, c)
+        assert probe["alarms"].sum() > 0
