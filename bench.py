@@ -214,7 +214,7 @@ def main():
     if MODE == "window":
         spec.append(("hold", (C_ * 4,), I64, capi.IO_RECORD))
         spec.append(("probe", (C_,), I64, capi.IO_RECORD))
-        spec.append(("work", (C_ * 16,), I64, capi.IO_RECORD))                 # igdsp_window_work_bytes(C) = 8 segments x C x 16 B
+        spec.append(("work", (C_ * 48,), I64, capi.IO_RECORD))                 # igdsp_window_work_bytes(C) = 8 segments x C x 48 B
     if MODE == "depayload":
         spec.append(("len", (F_ * C_,), I16, capi.IO_RECORD))
         spec.append(("dense", (F_, C_, n), U8, capi.IO_BULK))

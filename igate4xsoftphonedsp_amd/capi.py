@@ -328,7 +328,9 @@ class Context:
     # -- ED-137 gated window
     @staticmethod
     def window(hold, gate_mode=GATE_ALWAYS, gate=None, probe=None, work=None, probe_alarm=0) -> Window:
-        return Window(gate_mode, probe_alarm, _ptr(hold), _ptr(gate), _ptr(probe), _ptr(work))
+        w = Window(gate_mode, probe_alarm, _ptr(hold), _ptr(gate), _ptr(probe), _ptr(work))
+        w._keep = (hold, gate, probe, work)          # the struct holds raw pointers: keep the tensors alive as long as it lives
+        return w
 
     def window_work_bytes(self, C_: int) -> int:
         return int(self.L.igdsp_window_work_bytes(C_))

@@ -672,7 +672,7 @@ int igdsp_decode_meter_packets_mixed(igdsp_ctx *ctx, const uint8_t *d_packets, c
 }
 
 // ---------------------------------------------------------------- ED-137 gated window (last clause)
-size_t igdsp_window_work_bytes(uint32_t n_channels) { return (size_t)kWinMaxSeg * n_channels * sizeof(uint4); }
+size_t igdsp_window_work_bytes(uint32_t n_channels) { return (size_t)kWinMaxSeg * 3u * n_channels * sizeof(uint4); }
 
 static int check_window(igdsp_ctx *ctx, const igdsp_window *win)
 {
@@ -729,12 +729,13 @@ int igdsp_decode_meter_window(igdsp_ctx *ctx, uint32_t layout, const uint8_t *d_
     const uint32_t alarm = win->probe_alarm ? win->probe_alarm : IGDSP_PROBE_ALARM;
     hipStream_t s = pick(ctx, stream);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (C % 64u == 0u && (win->d_probe == nullptr || win->d_work != nullptr)) {
+    if (C % 64u == 0u && win->d_work != nullptr) {
         // channel-group-major fused kernel: the windows live in registers; at least one unit per resident wave, a segment is
         // never shorter than 8 frames nor longer than 65 535 (silent / clipped counts of a unit are 16 bits)
         igdsp::WinArgs w;
-        w.hold = win->d_hold; w.gate = win->d_gate; w.work = win->d_probe ? static_cast<uint4 *>(win->d_work) : nullptr;
-        w.gate_mode = win->gate_mode; w.alarm = alarm; w.n_groups = C / 64u; w.F = F;
+        w.work = static_cast<uint4 *>(win->d_work);
+        w.gate_mask = ((win->gate_mode & IGDSP_GATE_SQU) ? 0x10000000u : 0u) | ((win->gate_mode & IGDSP_GATE_PTT) ? 0xe0000000u : 0u);   // Functions.cpp:1160, 1136
+        w.alarm = alarm; w.n_groups = C / 64u; w.F = F;
         const uint32_t want = (uint32_t)ctx->cus * 12u;
         uint32_t n_seg = w.n_groups >= want ? 1u : (want + w.n_groups - 1u) / w.n_groups;
         if (const char *e = std::getenv("IGDSP_WIN_NSEG")) n_seg = (uint32_t)std::max(1, std::atoi(e));   // experiments
@@ -742,11 +743,11 @@ int igdsp_decode_meter_window(igdsp_ctx *ctx, uint32_t layout, const uint8_t *d_
         if (F / n_seg > 65535u) return fail(ctx, IGDSP_ERANGE, "decode_meter_window: more than 8 x 65535 frames per launch");
         w.n_seg = n_seg;
         HIP_TRY(ctx, launch_decode_meter_rtp(cfg_of(ctx, s), d_packets, sizes, d_codec, C, F, stride, hdr, d_stats, d_info, d_agg, rank, s, radio, &w));
-        if (win->d_probe) HIP_TRY(ctx, launch_window_finish(w.work, C, n_seg, alarm, win->d_probe, s));
+        HIP_TRY(ctx, launch_window_finish(w.work, C, n_seg, alarm, win->d_hold, win->d_gate, win->d_probe, s));
         return IGDSP_OK;
     }
     // other channel counts: the plain fused kernel, then the record-wise window fold on the same stream
-    if (!d_info) return fail(ctx, IGDSP_EINVAL, "decode_meter_window: channel counts that are not multiples of 64 (or probe tracking without d_work) need d_info");
+    if (!d_info) return fail(ctx, IGDSP_EINVAL, "decode_meter_window: channel counts that are not multiples of 64 (or a window without d_work) need d_info");
     HIP_TRY(ctx, launch_decode_meter_rtp(cfg_of(ctx, s), d_packets, sizes, d_codec, C, F, stride, hdr, d_stats, d_info, d_agg, rank, s, radio));
     HIP_TRY(ctx, launch_window_update(d_stats, d_info, nullptr, C, F, IGDSP_SAMPLES_PER_FRAME, win->gate_mode, alarm, win->d_hold, win->d_gate, win->d_probe, s));
     return IGDSP_OK;
@@ -865,6 +866,16 @@ int igdsp_internal_stream_pieces(igdsp_ctx *ctx, const void *d_src, uint32_t n_i
     if (!ctx || !d_src || !d_dst || (stride & 3u) || stride < 16u * (uint32_t)(rows - (mode == 0 ? 2 : 1))) return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_stream_pieces(cfg_of(ctx, pick(ctx, stream)), d_src, n_items, stride, hdr, mode, rows, d_dst, d_dst2, pick(ctx, stream)));
+    return IGDSP_OK;
+}
+
+// Calibration-only (not in include/igdsp.h): the packed-packet piece stream in the channel-group-major order of the fused window kernel
+int igdsp_internal_stream_walk(igdsp_ctx *ctx, const void *d_src, uint32_t n_items, uint32_t stride, uint32_t hdr, uint32_t groups, uint32_t n_seg,
+                               uint32_t trickle, void *d_dst, void *d_dst2, void *stream)
+{
+    if (!ctx || !d_src || !d_dst || (stride & 3u) || n_seg == 0 || (groups && n_items % groups)) return IGDSP_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_stream_walk(cfg_of(ctx, pick(ctx, stream)), d_src, n_items, stride, hdr, groups, n_seg, trickle, d_dst, d_dst2, pick(ctx, stream)));
     return IGDSP_OK;
 }
 

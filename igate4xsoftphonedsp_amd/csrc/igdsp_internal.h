@@ -25,14 +25,14 @@ struct LaunchCfg {
     bool out_spread = false;   // the launch's bulk output sits half in one, half in another memory class (igdsp_io_alloc)
 };
 
-// The ED-137 gated window of a fused packet launch (igdsp_decode_meter_window): hold / gate / work as in igdsp_window, work =
-// uint4[n_seg][C] run summaries or nullptr (no probe tracking); a unit = (one of n_groups = C / 64 channel groups, one of n_seg
-// segments of the F frames).
+// The ED-137 gated window of a fused packet launch (igdsp_decode_meter_window): work = uint4[n_seg][3][C] unit summaries (window
+// words 0, 1 and the silence-run word, k_window_finish); a unit = (one of n_groups = C / 64 channel groups, one of n_seg segments
+// of the F frames).
 struct WinArgs {
-    igdsp_chan_hold *hold = nullptr; const uint8_t *gate = nullptr; uint4 *work = nullptr;
-    uint32_t gate_mode = 0, alarm = IGDSP_PROBE_ALARM, n_seg = 1, n_groups = 0, F = 0;
+    uint4 *work = nullptr;
+    uint32_t gate_mask = 0, alarm = IGDSP_PROBE_ALARM, n_seg = 1, n_groups = 0, F = 0;   // gate_mask: ED-137 bits that open the frame gate (0 = always)
 };
-constexpr uint32_t kWinMaxSeg = 8;                       // igdsp_window_work_bytes = kWinMaxSeg x C x 16
+constexpr uint32_t kWinMaxSeg = 8;                       // igdsp_window_work_bytes = kWinMaxSeg x C x 48
 
 hipError_t init_device_attributes();       // per-device kernel attributes; igdsp_create calls it with its device current
 hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant,
@@ -47,7 +47,8 @@ hipError_t launch_decode_meter_rtp(const LaunchCfg &cfg, const uint8_t *slots, c
 // run summaries into probe[c]
 hipError_t launch_window_update(const igdsp_frame_stats *stats, const igdsp_rtp_info *info, const uint16_t *len, uint32_t C, uint32_t F, uint32_t n,
                                 uint32_t gate_mode, uint32_t alarm, igdsp_chan_hold *hold, const uint8_t *gate, igdsp_chan_probe *probe, hipStream_t s);
-hipError_t launch_window_finish(const uint4 *work, uint32_t C, uint32_t n_seg, uint32_t alarm, igdsp_chan_probe *probe, hipStream_t s);
+hipError_t launch_window_finish(const uint4 *work, uint32_t C, uint32_t n_seg, uint32_t alarm, igdsp_chan_hold *hold, const uint8_t *gate,
+                                igdsp_chan_probe *probe, hipStream_t s);
 hipError_t launch_diag_chunk32(const LaunchCfg &cfg, const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F,
                                igdsp_frame_stats *stats, uint64_t *diag, hipStream_t s);
 hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t *codec,
@@ -72,6 +73,8 @@ hipError_t launch_g726(const LaunchCfg &cfg, const uint8_t *in, uint8_t *out, ui
 hipError_t launch_gen_uniform(uint8_t *out, uint64_t n_bytes, uint64_t seed, uint64_t first_byte, hipStream_t s);
 hipError_t launch_stream_rw(const LaunchCfg &cfg, const void *src, size_t bytes, void *dst, hipStream_t s);
 hipError_t launch_stream_pieces(const LaunchCfg &cfg, const void *src, uint32_t n_items, uint32_t stride, uint32_t hdr, int mode, int rows, void *dst, void *dst2, hipStream_t s);
+hipError_t launch_stream_walk(const LaunchCfg &cfg, const void *src, uint32_t n_items, uint32_t stride, uint32_t hdr, uint32_t groups, uint32_t n_seg,
+                              uint32_t trickle, void *dst, void *dst2, hipStream_t s);
 hipError_t launch_stream_mix(const LaunchCfg &cfg, const void *src, void *dst, uint32_t n_items, int r, int w, int waves, hipStream_t s, void *dst2 = nullptr, const void *src2 = nullptr);
 hipError_t launch_stream_read(const LaunchCfg &cfg, const void *src, size_t bytes, uint64_t *sink, hipStream_t s);
 

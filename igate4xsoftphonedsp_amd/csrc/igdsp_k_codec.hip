@@ -1091,22 +1091,36 @@ __global__ __launch_bounds__(256) void k_window_update(const igdsp_frame_stats *
     if (probe) probe[c] = p;
 }
 
-// Chain the per-segment run summaries of a fused window launch (k_meter_rtp64<WIN>) into probe[c], in segment order:
-// summary = {probe frames before the segment's first reset (all of them if it had none), run at its end, alarms after its first
-// reset, had a reset}.  The leading frames continue the incoming run and raise an alarm if they carry it across the alarm length.
+// Fold the per-unit summaries of a fused window launch (k_meter_rtp64<WIN>) into hold[c] / probe[c], segments in frame order:
+// work[seg][0][c] = {sumsq lo, sumsq hi, frames, byte-mean sum}, [1] = {samples, peak_hold | level_max << 16, level_min, n_silent |
+// n_clipped << 16}, [2] = {probe frames before the segment's first reset (all of them if it had none), run at its end, alarms after
+// its first reset, had a reset}.  The leading probe frames of a segment continue the incoming run and raise an alarm if they carry
+// it across the alarm length.  gate[c] == 0 (the caller's per-channel window state) leaves hold[c] alone.
 __global__ __launch_bounds__(256) void k_window_finish(const uint4 *__restrict__ work, uint32_t C, uint32_t n_seg, uint32_t alarm,
+                                                       igdsp_chan_hold *__restrict__ hold, const uint8_t *__restrict__ gate,
                                                        igdsp_chan_probe *__restrict__ probe)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    igdsp_chan_probe p = probe[c];
+    const bool open = gate == nullptr || gate[c] != 0;
+    igdsp_chan_hold h = hold[c];
+    igdsp_chan_probe p = probe ? probe[c] : igdsp_chan_probe{0u, 0u};
     for (uint32_t sg = 0; sg < n_seg; ++sg) {
-        const uint4 w = work[(uint64_t)sg * C + c];
-        if (p.run < alarm && p.run + w.x >= alarm) p.alarms += 1u;
-        p.run = w.w ? w.y : p.run + w.y;
-        p.alarms += w.z;
+        const uint4 *wk = work + ((uint64_t)sg * 3u * C + c);
+        const uint4 a = wk[0], b = wk[C], r = wk[2u * (uint64_t)C];
+        if (open && a.z != 0u) {
+            h.sumsq_acc += ((uint64_t)a.y << 32) | a.x; h.count += a.z; h.level_sum += a.w; h.samples += b.x;
+            h.peak_hold = (uint16_t)max((uint32_t)h.peak_hold, b.y & 0xFFFFu);
+            h.level_max = (uint8_t)max((uint32_t)h.level_max, b.y >> 16);
+            h.level_min = (uint8_t)min((uint32_t)h.level_min, b.z);
+            h.n_silent += b.w & 0xFFFFu; h.n_clipped += b.w >> 16;
+        }
+        if (p.run < alarm && p.run + r.x >= alarm) p.alarms += 1u;
+        p.run = r.w ? r.y : p.run + r.y;
+        p.alarms += r.z;
     }
-    probe[c] = p;
+    if (open) hold[c] = h;
+    if (probe) probe[c] = p;
 }
 
 hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t *codec, uint32_t C, uint32_t F,
@@ -1241,10 +1255,11 @@ hipError_t launch_window_update(const igdsp_frame_stats *stats, const igdsp_rtp_
     return hipGetLastError();
 }
 
-hipError_t launch_window_finish(const uint4 *work, uint32_t C, uint32_t n_seg, uint32_t alarm, igdsp_chan_probe *probe, hipStream_t s)
+hipError_t launch_window_finish(const uint4 *work, uint32_t C, uint32_t n_seg, uint32_t alarm, igdsp_chan_hold *hold, const uint8_t *gate,
+                                igdsp_chan_probe *probe, hipStream_t s)
 {
     if (C == 0 || n_seg == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_window_finish, dim3((C + 255) / 256), dim3(256), 0, s, work, C, n_seg, alarm, probe);
+    hipLaunchKernelGGL(k_window_finish, dim3((C + 255) / 256), dim3(256), 0, s, work, C, n_seg, alarm, hold, gate, probe);
     return hipGetLastError();
 }
 

@@ -399,6 +399,65 @@ __global__ __launch_bounds__(768) void k_stream_pieces(const uint8_t *__restrict
     }
 }
 
+// The same compute-free packet-piece stream in the channel-group-major order of k_meter_rtp64<WIN>: a wave takes one unit =
+// (group g of `groups`, segment of the F = n_items / groups frames) and walks its frames, item f * groups + g; the loads of the
+// next item are issued before the current one is consumed (one item of lookahead, as the product kernel keeps).  Calibration only:
+// what the walk itself costs the memory system against the ascending order of k_stream_pieces.
+__global__ __launch_bounds__(768) void k_stream_walk(const uint8_t *__restrict__ src, uint32_t n_items, uint32_t stride, uint32_t hdr,
+                                                      uint32_t groups, uint32_t n_seg, uint32_t trickle, uint4 *__restrict__ dst, uint2 *__restrict__ dst2)
+{
+    // groups == 0: ascending order instead (wave k of the grid takes items k, k + waves, ...), same one-item lookahead.
+    // trickle != 0: the twelve loads of the next item go out one by one with s_sleep(trickle) between them, the way the product
+    // kernels re-load a piece register the moment it has been folded, instead of back to back.
+    constexpr int ROWS = 12;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    uint32_t po[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const uint32_t p = (uint32_t)j * 64u + lane, f = p / (uint32_t)ROWS, q = p - f * (uint32_t)ROWS;
+        po[j] = f * stride + (q == 0u ? 0u : (q == 1u ? 4u : hdr + 16u * (q - 2u)));
+    }
+    const uint32_t total = gridDim.x * wpb;
+    const bool asc = groups == 0u;
+    if (asc) { groups = 1u; n_seg = 1u; }
+    const uint32_t F = n_items / groups;
+    for (uint32_t unit = asc ? blockIdx.x * wpb + wave : wave * gridDim.x + blockIdx.x; unit < (asc ? total : groups * n_seg); unit += total) {
+        const uint32_t seg = asc ? 0u : unit / groups, g = asc ? unit : unit - seg * groups, step = asc ? total : groups;
+        const uint32_t i_lo = asc ? g : (uint32_t)(((uint64_t)F * seg) / n_seg) * groups + g;
+        const uint32_t i_hi = asc ? n_items : (uint32_t)(((uint64_t)F * (seg + 1u)) / n_seg) * groups;
+        if (i_lo >= i_hi) continue;
+        uint4 v[ROWS];
+        {
+            const uint8_t *base = src + (uint64_t)i_lo * 64u * stride;
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) v[j] = ld16_dw(base + po[j]);
+        }
+        for (uint32_t item = i_lo; item < i_hi; item += step) {
+            const uint32_t nxt = item + step < i_hi ? item + step : item;
+            const uint8_t *nb = src + (uint64_t)nxt * 64u * stride;
+            uint4 acc = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                acc.x ^= v[j].x; acc.y ^= v[j].y; acc.z ^= v[j].z; acc.w ^= v[j].w;
+                v[j] = ld16_dw(nb + po[j]);
+                if (trickle == 1u) __builtin_amdgcn_s_sleep(4);
+                if (trickle == 2u) __builtin_amdgcn_s_sleep(16);
+                if (trickle == 3u) __builtin_amdgcn_s_sleep(48);
+            }
+            dst[(uint64_t)item * 64u + lane] = acc;
+            if (dst2 != nullptr) dst2[(uint64_t)item * 64u + lane] = make_uint2(acc.x, acc.y);
+        }
+    }
+}
+
+hipError_t launch_stream_walk(const LaunchCfg &cfg, const void *src, uint32_t n_items, uint32_t stride, uint32_t hdr, uint32_t groups, uint32_t n_seg,
+                              uint32_t trickle, void *dst, void *dst2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_stream_walk, dim3(cfg.compute_units), dim3(768), 0, s, reinterpret_cast<const uint8_t *>(src), n_items, stride, hdr, groups, n_seg, trickle,
+                       reinterpret_cast<uint4 *>(dst), reinterpret_cast<uint2 *>(dst2));
+    return hipGetLastError();
+}
+
 hipError_t launch_stream_pieces(const LaunchCfg &cfg, const void *src, uint32_t n_items, uint32_t stride, uint32_t hdr, int mode, int rows, void *dst, void *dst2, hipStream_t s)
 {
     const dim3 g(cfg.compute_units), b(768);

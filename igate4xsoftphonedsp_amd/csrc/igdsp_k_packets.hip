@@ -115,9 +115,11 @@ __device__ __forceinline__ void meter_short(const uint2 *lut, const uint32_t off
 // 2126-2145, plus sum of squares, peak-hold, silent / clipped counts) and the consecutive-silence run (adapter->rtpFalse,
 // TransportAdapter.cpp:657-673) of each channel in the lane's registers.  The per-frame gate comes from the ED-137 word the frame
 // lane parses anyway (masks Functions.cpp:1136, 1160).  At a unit's last frame the window merges into hold[c] by integer
-// atomics (exact, order-free: bit-identical to the sequential fold; plain read-modify-write when there is one segment) and the
-// run leaves as a 16-byte summary {probe frames before the first reset, run at the end, alarms after the first reset, had a
-// reset} in work[seg][c], which k_window_finish chains in segment order.  The id stream of a wave carries the unit's segment
+// atomics would be possible (exact, order-free) but all units end together and the burst costs 12 % of the launch; instead the
+// unit's window {sum of squares, frames, byte-mean sum | samples, peak-hold | level-max, level-min, silent | clipped} and its run
+// {probe frames before the first reset, run at the end, alarms after the first reset, had a reset} leave as three 16-byte words in
+// work[seg][k][c], which k_window_finish folds into hold[c] / probe[c] in segment order (integer sums, max, min: bit-identical
+// to the sequential fold).  The id stream of a wave carries the unit's segment
 // (bits 27-29) and a last-frame-of-unit flag (bit 31), so the load pipeline runs straight across unit boundaries.
 template <bool AGG, bool SLOT, bool MIXED = false, bool WIN = false>
 __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
@@ -134,9 +136,9 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);
     fill_lut(lds);
     if (threadIdx.x == 0) { bq_init(bq, gqueue, gridDim.x, gb1); agg_block_init(aggb); }
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     __syncthreads();
 
-    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint2 *strip = lds + kLutEntries + wave * kRtpStrip;
     const uint32_t off = (lane & 31u) * 8u;
     uint32_t pm[kRtpHalfLoads], fr[kRtpHalfLoads];        // fr = slot within the half | header-piece selector << 8 (shifts and v_bfe only look at the low 5 bits)
@@ -181,23 +183,28 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     const uint32_t n_batches = IGDSP_SPREAD_METER ? (n_super + (uint32_t)kRtpWaves - 1u) / (uint32_t)kRtpWaves : 0u;   // records only: no spreading
     // WIN: the wave's id stream = its units (round r: unit r * total_waves + wave * G + block, the roundtrip kernels' "a grid
     // apart" order), each walked in frame order; wave-uniform state in SGPRs
-    uint32_t w_round = 0, w_g = 0, w_seg = 0, w_f = 0, w_fhi = 0;
+    // (kept minimal: the packed-packet kernel already runs at the rate of a compute-free kernel with its access pattern, so
+    // every instruction added per item shows — a first version with 64-bit unit arithmetic and the unit's frame bounds live across
+    // the loop executed twice the scalar and 10 % more vector instructions and ran 10 % slower)
+    uint32_t w_next = 0, w_left = 0, w_seg = 0, w_unit = wave * G + blockIdx.x;          // next id, frames left in the unit, its segment, next unit
+    const uint32_t w_units = win.n_groups * win.n_seg, w_stride = G * (uint32_t)kRtpWaves;   // (< 2^27: the launcher)
     auto grab = [&]() -> uint32_t {
         if (!WIN) return bq_grab(bq, gqueue, G, lane, n_batches);
-        for (;;) {
-            if (w_f < w_fhi) {
-                const uint32_t id = (w_f * win.n_groups + w_g) | (w_seg << 27) | ((w_f + 1u == w_fhi) ? 0x80000000u : 0u);
-                ++w_f;
-                return id;
-            }
-            const uint64_t unit = (uint64_t)w_round * (G * (uint32_t)kRtpWaves) + (wave * G + blockIdx.x);
-            if (unit >= (uint64_t)win.n_groups * win.n_seg) return 0xFFFFFFFFu;
-            ++w_round;
-            w_seg = (uint32_t)(unit / win.n_groups);
-            w_g = (uint32_t)unit - w_seg * win.n_groups;
-            w_f = (uint32_t)(((uint64_t)win.F * w_seg) / win.n_seg);
-            w_fhi = (uint32_t)(((uint64_t)win.F * (w_seg + 1u)) / win.n_seg);
+#ifdef IGDSP_WIN_ASC              // A/B builds only (wrong windows on purpose): the WIN code over the ascending static item order
+        { const uint32_t id = w_unit; w_unit += w_stride; return id < n_super ? id : 0xFFFFFFFFu; }
+#endif
+        if (w_left == 0u) {
+            if (w_unit >= w_units) return 0xFFFFFFFFu;
+            w_seg = w_unit / win.n_groups;
+            const uint32_t f_lo = (uint32_t)(((uint64_t)win.F * w_seg) / win.n_seg);
+            w_left = (uint32_t)(((uint64_t)win.F * (w_seg + 1u)) / win.n_seg) - f_lo;     // >= 1: n_seg <= F (the launcher)
+            w_next = f_lo * win.n_groups + (w_unit - w_seg * win.n_groups);
+            w_unit += w_stride;
         }
+        const uint32_t id = w_next | (w_seg << 27) | (w_left == 1u ? 0x80000000u : 0u);
+        w_next += win.n_groups;
+        w_left -= 1u;
+        return id;
     };
     auto id_ok = [&](uint32_t id) { return WIN ? id != 0xFFFFFFFFu : id < n_super; };
     auto id_sidx = [&](uint32_t id) { return WIN ? (id & 0x07FFFFFFu) : id; };
@@ -317,39 +324,34 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
                     u_clip += (uint32_t)__builtin_popcountll(__ballot(metered && (fl & IGDSP_FLAG_CLIPPED) != 0u));
                 }
                 if (WIN) {
+#ifndef IGDSP_WIN_NOBOOK          // A/B builds only: the walk without the per-frame bookkeeping (wrong windows on purpose)
+                    // branch-free: every step is a select on the lane's own predicates
                     const uint32_t l = whole ? (uint32_t)kFrame : plen;
                     // consecutive-silence run: only a metered frame that holds the probe bytes (payload length > 48) moves it
-                    if (metered && l > 48u) {
-                        if ((fl & IGDSP_FLAG_PROBE_D5) != 0u) {
-                            r_trail += 1u;
-                            r_hits += ((r_lead >> 31) != 0u && r_trail == win.alarm) ? 1u : 0u;
-                        } else {
-                            if ((r_lead >> 31) == 0u) r_lead = r_trail | 0x80000000u;
-                            r_trail = 0u;
-                        }
-                    }
-                    // frame gate from the ED-137 word of this frame's own packet (PTT type bits 31-29, SQU bit 28)
-                    const uint32_t squ = (ed >> 28) & 1u, ptt = ed >> 29;
-                    const bool g = win.gate_mode == IGDSP_GATE_ALWAYS || (win.gate_mode == IGDSP_GATE_SQU && squ != 0u) ||
-                                   (win.gate_mode == IGDSP_GATE_PTT && ptt != 0u) || (win.gate_mode == IGDSP_GATE_SQU_OR_PTT && (squ | ptt) != 0u);
-                    if (metered && g) {
-                        w_sumsq += s << 4; w_cnt += 1u; w_lsum += bm; w_samp += l;
-                        w_pm = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16_t, w_pm), __builtin_bit_cast(v2u16_t, peak | (bm << 16))));
-                        w_min = min(w_min, bm);
-                        w_sc += ((fl & IGDSP_FLAG_SILENT) ? 1u : 0u) + ((fl & IGDSP_FLAG_CLIPPED) ? 0x10000u : 0u);
-                    }
+                    const bool valid = metered && l > 48u, pr = valid && (fl & IGDSP_FLAG_PROBE_D5) != 0u, npr = valid && !pr;
+                    const uint32_t nt = r_trail + (pr ? 1u : 0u);
+                    r_hits += (pr && (r_lead >> 31) != 0u && nt == win.alarm) ? 1u : 0u;
+                    r_lead = (npr && (r_lead >> 31) == 0u) ? (r_trail | 0x80000000u) : r_lead;
+                    r_trail = npr ? 0u : nt;
+                    // frame gate from the ED-137 word of this frame's own packet: win.gate_mask = SQU bit 28 and / or PTT type bits
+                    // 31-29 (Functions.cpp:1160, 1136); 0 = every metered frame
+                    const bool fold = metered && (win.gate_mask == 0u || (ed & win.gate_mask) != 0u);
+                    w_sumsq += fold ? (s << 4) : 0ull;
+                    w_cnt += fold ? 1u : 0u; w_lsum += fold ? bm : 0u; w_samp += fold ? l : 0u;
+                    w_pm = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16_t, w_pm), __builtin_bit_cast(v2u16_t, fold ? (peak | (bm << 16)) : 0u)));
+                    w_min = min(w_min, fold ? bm : 255u);
+                    w_sc += fold ? (((fl & IGDSP_FLAG_SILENT) ? 1u : 0u) + ((fl & IGDSP_FLAG_CLIPPED) ? 0x10000u : 0u)) : 0u;
+#endif
                     if ((id_cur >> 31) != 0u) {             // wave-uniform: last frame of the unit
+                        // the unit's window and run leave as three 16-byte words per channel, work[seg][k][c] (64 lanes = 1 KiB per
+                        // store); k_window_finish chains the segments of a channel in order.  (A first version merged the
+                        // windows into hold[c] with device atomics at this point: all units end together, and the burst of
+                        // 7 atomics x 64 lanes x 3 072 waves cost the launch 12 %.)
                         const uint32_t cme = (sidx % win.n_groups) * (uint32_t)kSuperFrames + lane, seg = (id_cur >> 27) & 7u;
-                        if (w_cnt != 0u && (win.gate == nullptr || win.gate[cme] != 0)) {
-                            igdsp_chan_hold h;
-                            h.sumsq_acc = w_sumsq; h.count = w_cnt; h.level_sum = w_lsum; h.samples = w_samp;
-                            h.peak_hold = (uint16_t)(w_pm & 0xFFFFu); h.level_max = (uint8_t)(w_pm >> 16); h.level_min = (uint8_t)w_min;
-                            h.n_silent = w_sc & 0xFFFFu; h.n_clipped = w_sc >> 16;
-                            if (win.n_seg == 1u) hold_add(win.hold + cme, h);       // the wave owns hold[c]: plain read-modify-write
-                            else hold_merge(win.hold + cme, h);
-                        }
-                        if (win.work != nullptr)
-                            win.work[(uint64_t)seg * C + cme] = make_uint4((r_lead >> 31) ? (r_lead & 0x7FFFFFFFu) : r_trail, r_trail, r_hits, r_lead >> 31);
+                        uint4 *wk = win.work + ((uint64_t)seg * 3u * C + cme);
+                        wk[0] = make_uint4((uint32_t)w_sumsq, (uint32_t)(w_sumsq >> 32), w_cnt, w_lsum);
+                        wk[C] = make_uint4(w_samp, w_pm, w_min, w_sc);
+                        wk[2u * (uint64_t)C] = make_uint4((r_lead >> 31) ? (r_lead & 0x7FFFFFFFu) : r_trail, r_trail, r_hits, r_lead >> 31);
                         w_sumsq = 0; w_cnt = 0; w_lsum = 0; w_samp = 0; w_pm = 0; w_min = 255u; w_sc = 0;
                         r_trail = 0; r_lead = 0; r_hits = 0;
                     }
@@ -568,16 +570,11 @@ hipError_t launch_decode_meter_rtp(const LaunchCfg &cfg, const uint8_t *slots, c
     if (win != nullptr) {
         const uint32_t grid = blocks_for((uint64_t)win->n_groups * win->n_seg, kRtpWaves, (uint32_t)cfg.compute_units);
         uint32_t *noq = nullptr;                           // units are assigned statically (a grid apart), no device queue
-        if (stride == 0) {
-            if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, true, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, noq, radio, *win);
-            else     hipLaunchKernelGGL((k_meter_rtp64<false, true, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, noq, radio, *win);
-        } else if (radio != nullptr) {
-            if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false, true, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, noq, radio, *win);
-            else     hipLaunchKernelGGL((k_meter_rtp64<false, false, true, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, noq, radio, *win);
-        } else {
-            if (agg) hipLaunchKernelGGL((k_meter_rtp64<true, false, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, noq, radio, *win);
-            else     hipLaunchKernelGGL((k_meter_rtp64<false, false, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, noq, radio, *win);
-        }
+        // (one instantiation per layout: without an aggregate the AGG code still runs and wave_exit drops the totals — the
+        // aggregate-free packed instantiation needed 170 VGPRs and spilled)
+        if (stride == 0)          hipLaunchKernelGGL((k_meter_rtp64<true, true, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, noq, radio, *win);
+        else if (radio != nullptr) hipLaunchKernelGGL((k_meter_rtp64<true, false, true, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, noq, radio, *win);
+        else                       hipLaunchKernelGGL((k_meter_rtp64<true, false, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, noq, radio, *win);
         return hipGetLastError();
     }
     const uint32_t grid = blocks_for(n_frames / kSuperFrames, kRtpWaves, (uint32_t)cfg.compute_units);

@@ -367,9 +367,9 @@ typedef struct igdsp_window {
     igdsp_chan_hold *d_hold;      /* [C] window aggregate the gated frames are folded into (required)                */
     const uint8_t *d_gate;        /* [C] optional per-channel window state, 0 = closed                               */
     igdsp_chan_probe *d_probe;    /* [C] optional consecutive-silence state                                          */
-    void *d_work;                 /* igdsp_window_work_bytes(C) bytes of device scratch, 16-byte aligned: required by */
-                                  /* igdsp_decode_meter_window when d_probe is given (per-segment run summaries);    */
-                                  /* not used by igdsp_window_update.  One buffer per stream that launches            */
+    void *d_work;                 /* igdsp_window_work_bytes(C) bytes of device scratch, 16-byte aligned (48 B x 8 x C): */
+                                  /* the per-segment window / run summaries of igdsp_decode_meter_window's fused kernel; */
+                                  /* not used by igdsp_window_update.  One buffer per stream that launches               */
 } igdsp_window;
 size_t igdsp_window_work_bytes(uint32_t n_channels);
 
@@ -385,9 +385,10 @@ int igdsp_window_update(igdsp_ctx *ctx, const igdsp_frame_stats *d_stats, const 
  *   IGDSP_PKT_SLOTS  = igdsp_decode_meter_rtp            (192-byte slots; d_sizes, d_radio, pkt_stride, hdr_bytes ignored)
  *   IGDSP_PKT_PACKED = igdsp_decode_meter_packets        (pkt_stride, hdr_bytes 12 / 20, optional d_sizes; d_radio ignored)
  *   IGDSP_PKT_MIXED  = igdsp_decode_meter_packets_mixed  (pkt_stride, d_radio, optional d_sizes; hdr_bytes ignored)
- * Same argument rules and records as those entries.  With n_channels % 64 == 0 the kernel walks channel groups (a wavefront
- * keeps 64 channels' windows in registers over a segment of the frames and merges them with integer atomics: exact and
- * order-free, bit-identical to the sequential fold); other channel counts run the plain fused kernel followed by
+ * Same argument rules and records as those entries.  With n_channels % 64 == 0 and win->d_work given the kernel walks
+ * channel groups (a wavefront keeps 64 channels' windows and silence runs in registers over a segment of the frames; the
+ * segments' summaries go through d_work and are folded in frame order by a small second kernel: integer sums / max / min,
+ * bit-identical to the sequential fold); other channel counts, or d_work == NULL, run the plain fused kernel followed by
  * igdsp_window_update on the same stream; d_info has to be given then (it carries each frame's ED-137 word and length). */
 #define IGDSP_PKT_SLOTS   0u
 #define IGDSP_PKT_PACKED  1u

@@ -978,6 +978,7 @@ def test_flush_gates_by_ed137_word_and_follows_the_silence_run(orc):
         for ch in range(nch):
             c.map_call(500 + ch, ch)
         rng = np.random.default_rng(5)
+        words = {}                                                        # the calls' current ED-137 words persist across the modes
         for mode in (capi.GATE_SQU, capi.GATE_PTT, capi.GATE_SQU_OR_PTT, capi.GATE_ALWAYS):
             c.set_gate_mode(mode)
             c.reset_hold()
@@ -994,8 +995,8 @@ def test_flush_gates_by_ed137_word_and_follows_the_silence_run(orc):
                         if rng.integers(0, 3) == 0:
                             word = int(rng.integers(0, 1 << 32)) if rng.integers(0, 2) else 0
                             c.set_ed137(500 + ch, word)
-                            last[("w", ch)] = word
-                        word = last.get(("w", ch), 0)
+                            words[ch] = word
+                        word = words.get(ch, 0)
                         ln = 160 if rng.integers(0, 4) else int(rng.choice([24, 48, 52, 164, 255]))
                         pl = np.full(ln, 0xD5, np.uint8) if rng.integers(0, 2) else orc.gen_uniform(ln, seed=tick * 100000 + ch * 10 + j)
                         assert c.on_rtp_frame(500 + ch, 8, pl.tobytes()) == 0
