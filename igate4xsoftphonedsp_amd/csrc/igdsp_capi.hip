@@ -209,6 +209,7 @@ int igdsp_destroy(igdsp_ctx *ctx)
     if (!ctx) return IGDSP_OK;                       // tolerate NULL like the reference's setters (TransportAdapter.cpp:135-223)
     delete ctx->pool;
     if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+    igdsp_io_drop_spares(ctx);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     if (ctx->flush_done) (void)hipEventDestroy(ctx->flush_done);
     void *hosts[] = {ctx->h_ring, ctx->h_rlen, ctx->h_rpt, ctx->h_red, ctx->h_up, ctx->pub[0].last, ctx->pub[0].hold, ctx->pub[0].probe,
@@ -856,6 +857,15 @@ int igdsp_internal_stream_rw(igdsp_ctx *ctx, const void *d_src, size_t bytes, vo
     if (!ctx || !d_src || !d_dst || (reinterpret_cast<uintptr_t>(d_src) & 15u) || (reinterpret_cast<uintptr_t>(d_dst) & 15u)) return IGDSP_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_stream_rw(cfg_of(ctx, pick(ctx, stream)), d_src, bytes, d_dst, pick(ctx, stream)));
+    return IGDSP_OK;
+}
+
+// Calibration-only (not in include/igdsp.h): the meter's 10 : 1 traffic with the record stores of k consecutive super-chunks clustered
+int igdsp_internal_stream_cluster(igdsp_ctx *ctx, const void *d_src, size_t bytes, void *d_dst, int k, void *stream)
+{
+    if (!ctx || !d_src || !d_dst || ((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(d_dst)) & 15u)) return IGDSP_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_stream_cluster(cfg_of(ctx, pick(ctx, stream)), d_src, bytes, d_dst, k, pick(ctx, stream)));
     return IGDSP_OK;
 }
 

@@ -30,6 +30,15 @@ struct igdsp_ctx {
     // pick the traversal that suits that placement (launch_roundtrip)
     struct IoRange { const char *base; size_t bytes; };
     std::vector<IoRange> spread_ranges;
+    // igdsp_io_alloc's memory of what it learnt: spare 128 MiB chunks of physical memory whose class a search (or a freed buffer
+    // set) has established, kept mapped nowhere, up to io_spare_cap per class.  Class of a chunk = a property of the physical
+    // memory, so only chunks that are HELD keep it; a later igdsp_io_alloc that these cover maps them without a single probe
+    // (and releases nothing, so there is no driver clearing to wait out).  Labels are the context's own: 0 = the class the first
+    // search's inputs landed in, 1 = "not 0" (not split further), 2 / 3 = the two other classes once a bulk search split them.
+    std::vector<hipMemGenericAllocationHandle_t> io_spare[4];
+    size_t io_spare_chunk = 0;                          // chunk size the spares were created with
+    size_t io_spare_cap = 16;                           // chunks kept per class (IGDSP_IO_SPARE_CHUNKS; 0 = keep none)
+    uint32_t io_epoch = 0;                              // moves with every full search: class labels of older buffer sets no longer apply
     std::mutex io_mu;
     bool is_spread(const void *p)
     {
@@ -105,6 +114,8 @@ namespace {
 constexpr uint32_t kQueueRing = 64;
 const hipStream_t kFreeQueue = reinterpret_cast<hipStream_t>(~(uintptr_t)0);   // not a stream handle (NULL is one: the legacy default stream)
 }
+
+void igdsp_io_drop_spares(igdsp_ctx *ctx);             // igdsp_io.hip: give the spare chunks back (igdsp_destroy, and before a new search)
 
 static inline int fail(igdsp_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess)
 {

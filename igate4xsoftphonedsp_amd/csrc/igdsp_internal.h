@@ -72,6 +72,7 @@ hipError_t launch_wav_expand(const LaunchCfg &cfg, const uint8_t *payload, uint3
 hipError_t launch_g726(const LaunchCfg &cfg, const uint8_t *in, uint8_t *out, uint64_t n_bytes, int mode, hipStream_t s);
 hipError_t launch_gen_uniform(uint8_t *out, uint64_t n_bytes, uint64_t seed, uint64_t first_byte, hipStream_t s);
 hipError_t launch_stream_rw(const LaunchCfg &cfg, const void *src, size_t bytes, void *dst, hipStream_t s);
+hipError_t launch_stream_cluster(const LaunchCfg &cfg, const void *src, size_t bytes, void *dst, int k, hipStream_t s);
 hipError_t launch_stream_pieces(const LaunchCfg &cfg, const void *src, uint32_t n_items, uint32_t stride, uint32_t hdr, int mode, int rows, void *dst, void *dst2, hipStream_t s);
 hipError_t launch_stream_walk(const LaunchCfg &cfg, const void *src, uint32_t n_items, uint32_t stride, uint32_t hdr, uint32_t groups, uint32_t n_seg,
                               uint32_t trickle, void *dst, void *dst2, hipStream_t s);

@@ -34,7 +34,9 @@
 using namespace igdsp;
 
 struct igdsp_io_set {
-    struct Map { void *va = nullptr; size_t bytes = 0; std::vector<hipMemGenericAllocationHandle_t> handles; };
+    // cls[i] = class label of handles[i] in the context's labelling (igdsp_ctx::io_spare; 255 = unknown), valid while epoch matches
+    struct Map { void *va = nullptr; size_t bytes = 0; std::vector<hipMemGenericAllocationHandle_t> handles; std::vector<uint8_t> cls; };
+    uint32_t epoch = 0;
     std::vector<Map> maps;            // VMM path: one reserved range per buffer, chunk handles mapped back to back
     std::vector<void *> plain;        // fallback path: hipMalloc'ed buffers
     size_t chunk = 0;
@@ -52,6 +54,7 @@ struct Chunk {
     bool used = false;                // handed to a buffer (not to be released)
     bool mapped = false;              // currently mapped on its scratch slot
     bool in_src = false;              // currently part of a probe source
+    int cls = -1;                     // class label once established (igdsp_ctx::io_spare), -1 unknown
 };
 
 // A probe source: kSrcChunks chunks mapped back to back on an address range of their own.  A range is mapped ONCE: on this
@@ -193,13 +196,31 @@ int igdsp_io_free(igdsp_ctx *ctx, igdsp_io_set *set)
     for (auto &m : set->maps) {
         if (!m.va) continue;
         for (size_t i = 0; i < m.handles.size(); ++i) (void)hipMemUnmap((char *)m.va + i * set->chunk, set->chunk);
-        for (auto h : m.handles) (void)hipMemRelease(h);
+        // a chunk whose class is known (and still labelled in the context's current terms) becomes a spare: the next
+        // igdsp_io_alloc can map it without probing, and nothing is released for the driver to clear
+        std::lock_guard<std::mutex> g(ctx->io_mu);
+        for (size_t i = 0; i < m.handles.size(); ++i) {
+            const uint8_t c = i < m.cls.size() ? m.cls[i] : 255;
+            if (c < 4 && set->epoch == ctx->io_epoch && set->chunk == ctx->io_spare_chunk && ctx->io_spare[c].size() < ctx->io_spare_cap) ctx->io_spare[c].push_back(m.handles[i]);
+            else (void)hipMemRelease(m.handles[i]);
+        }
     }
     for (void *p : set->plain) if (p) (void)hipFree(p);
     (void)hipGetLastError();
     delete set;
     return IGDSP_OK;
 }
+
+}  // extern "C"
+
+void igdsp_io_drop_spares(igdsp_ctx *ctx)
+{
+    std::lock_guard<std::mutex> g(ctx->io_mu);
+    for (auto &v : ctx->io_spare) { for (auto h : v) (void)hipMemRelease(h); v.clear(); }
+    (void)hipGetLastError();
+}
+
+extern "C" {
 
 // Diagnostic (not in include/igdsp.h): does a device address that was un-mapped and then mapped onto ANOTHER chunk reach
 // the new chunk?  Writes 0x11 through address v to chunk X, re-maps v onto chunk Y, writes 0x22 through v, then reads X and Y
@@ -333,8 +354,10 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
 
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    // default: 60 % of what is free; 85 % when bulk outputs want a THIRD class (the allocator tends to hand that one out last)
-    double dflt = bulk_chunks >= 8 ? 0.85 : 0.6;
+    // default: 50 % of what is free; 85 % when bulk outputs want a THIRD class (the allocator tends to hand that one out last).
+    // That is only the ceiling: the search stops as soon as every buffer has its chunks (typically 15-50 GB explored for a
+    // two-class set), and later calls are served from the spares this one leaves behind.
+    double dflt = bulk_chunks >= 8 ? 0.85 : 0.5;
     if (const char *e = std::getenv("IGDSP_IO_LIMIT_FRAC")) dflt = std::atof(e);
     size_t limit = explore_limit_bytes ? explore_limit_bytes : (size_t)(dflt * (double)free_b);
     limit = std::min(limit, (size_t)(0.9 * (double)free_b));
@@ -352,15 +375,68 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
         }
         ok = ok && map_chunks(m, chunk, hs, have, X.acc);
         m.handles.insert(m.handles.end(), hs.begin(), hs.end());      // owned by the set from here on (released by igdsp_io_free)
+        m.cls.resize(m.handles.size(), 255);                          // class unknown
         return ok;
     };
 
     // Below 512 MiB of inputs a launch works out of the 256 MiB Infinity Cache and placement does not matter.
     // (a set of INPUT buffers only is still worth placing once it is larger than the probe source: all of it lands in ONE class)
     const bool want_place = in_bytes >= ((size_t)512 << 20) && ((rec_chunks + bulk_chunks) > 0 || in_chunks > kSrcChunks) && limit / chunk >= 4 * kSrcChunks;
+    if (const char *e = std::getenv("IGDSP_IO_SPARE_CHUNKS")) ctx->io_spare_cap = (size_t)std::max(0, std::atoi(e));
+    // Served from what an earlier call learnt?  Spare chunks of known class (left by a search, or returned by igdsp_io_free)
+    // cover this set when the inputs fit class 0, the records and the bulk outputs' first halves fit the non-0 spares and the
+    // second halves the other non-0 class: map them, probe nothing, release nothing (so there is nothing to wait out either).
+    if (want_place) {
+        std::lock_guard<std::mutex> g(ctx->io_mu);
+        auto &S0 = ctx->io_spare[0], &S1 = ctx->io_spare[1], &S2 = ctx->io_spare[2], &S3 = ctx->io_spare[3];
+        const bool want_spread = bulk_chunks >= 8;
+        const size_t second = want_spread ? bulk_chunks / 2 : 0, first = rec_chunks + bulk_chunks - second;
+        if (ctx->io_spare_chunk == chunk && S0.size() >= in_chunks && S1.size() + S2.size() >= first && S3.size() >= second && (!want_spread || S2.size() + S1.size() >= first)) {
+            bool okf = true;
+            auto take = [&](std::vector<hipMemGenericAllocationHandle_t> &from, uint8_t label, igdsp_io_set::Map &m) {
+                m.handles.push_back(from.back()); m.cls.push_back(label); from.pop_back();
+            };
+            for (uint32_t role = 0; role < 3; ++role)
+                for (uint32_t i = 0; i < n_bufs; ++i) {
+                    if (bufs[i].role != role) continue;
+                    auto &m = set->maps[i];
+                    const size_t h2 = (role == IGDSP_IO_BULK && want_spread) ? nch[i] / 2 : 0;
+                    for (size_t k = 0; k < nch[i]; ++k) {
+                        if (role == IGDSP_IO_INPUT) take(S0, 0, m);
+                        else if (k >= nch[i] - h2 && !S3.empty()) take(S3, 3, m);
+                        else if (want_spread ? !S2.empty() : !S1.empty()) { if (want_spread) take(S2, 2, m); else take(S1, 1, m); }
+                        else if (!S2.empty()) take(S2, 2, m);
+                        else if (!S1.empty()) take(S1, 1, m);
+                        else take(S3, 3, m);
+                    }
+                    okf = okf && map_chunks(m, chunk, m.handles, 0, X.acc);
+                }
+            if (!okf) { (void)hipGetLastError(); return finish(fail(ctx, IGDSP_ENOMEM, "igdsp_io_alloc: mapping spare chunks")); }
+            set->epoch = ctx->io_epoch;
+            bool spread_ok = want_spread;
+            for (uint32_t i = 0; i < n_bufs && spread_ok; ++i)
+                if (bufs[i].role == IGDSP_IO_BULK) spread_ok = !set->maps[i].cls.empty() && set->maps[i].cls.front() != set->maps[i].cls.back();
+            R.placed = 1; R.bulk_spread = (spread_ok && bulk_chunks > 0) ? 1u : 0u; R.classes_found = R.bulk_spread ? 3u : 2u;
+            for (uint32_t i = 0; i < n_bufs; ++i) bufs[i].ptr = set->maps[i].va;
+            if (R.bulk_spread)
+                for (uint32_t i = 0; i < n_bufs; ++i)
+                    if (bufs[i].role == IGDSP_IO_BULK) ctx->spread_ranges.push_back({(const char *)set->maps[i].va, set->maps[i].bytes});
+            R.setup_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+            if (rep) *rep = R;
+            *out_set = set;
+            return IGDSP_OK;
+        }
+    }
     std::vector<size_t> poolA, poolB, poolC;        // chunk indices: class of the inputs / first other class / second other class
     bool ok = true;
+    float lab_fast = 0.f, lab_slow = 0.f, lab_thrB = 0.f, lab_thrC = 0.f;     // thresholds the search ended with (labels of the leftovers)
+    bool lab_split = false;
     if (want_place) {
+        // a full search re-establishes the class labels: spares and older buffer sets were labelled relative to ANOTHER search's
+        // inputs, which may have landed in a different class than this one's
+        igdsp_io_drop_spares(ctx);
+        { std::lock_guard<std::mutex> g(ctx->io_mu); ctx->io_epoch += 1; ctx->io_spare_chunk = chunk; }
+        set->epoch = ctx->io_epoch;
         X.probe_n = kSrcChunks * (chunk - 4096) / 10240 * 10240;       // a probe launch reads this much and writes 1/10 of it into the chunk under test
         X.limit_chunks = limit / chunk;
         X.cand_bytes = X.limit_chunks * chunk;
@@ -449,6 +525,7 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
         if (bimodal) {
             R.classes_found = 2;
             const float thr_fast = kNear * tmin, thr_slow = tmax / kNear;
+            lab_fast = thr_fast; lab_slow = thr_slow;
             auto fast_A = [&](size_t idx) { return !X.chunks[idx].in_src && timeA(idx) && X.chunks[idx].tA < thr_fast; };
             auto slow_A = [&](size_t idx) { return X.chunks[idx].in_src ? false : (timeA(idx) && X.chunks[idx].tA > thr_slow); };
             // Walk the chunk sequence from `idx` and collect `want` chunks that satisfy `pred` (which probes on demand): inside
@@ -592,9 +669,26 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
                         R.classes_found = 3;
                         poolB = cb;
                         poolC = cc;
+                        lab_split = true; lab_thrB = thrB; lab_thrC = thrC;
                     }
                 }
                 if (have_src) X.drop_source(srcB);
+            }
+            // Spares for the NEXT set of this size: chunks the sparse survey created but never timed are classified now — about
+            // 1.5 ms of probing each, no new memory — until each class has io_spare_cap of them beyond what this set takes; they stay
+            // with the context (below) and a later call that they cover is served without a search.
+            if (ok && !want_spread && ctx->io_spare_cap > 0) {
+                const size_t need0 = (in_chunks > kSrcChunks ? in_chunks - kSrcChunks : 0) + ctx->io_spare_cap, need1 = rec_chunks + bulk_chunks + ctx->io_spare_cap;
+                size_t cnt0 = 0, cnt1 = 0;
+                for (const auto &c : X.chunks) if (!c.in_src && c.tA >= 0.f) { if (c.tA > thr_slow) ++cnt0; else if (c.tA < thr_fast) ++cnt1; }
+                size_t budget = 4 * ctx->io_spare_cap;
+                for (size_t k = 0; k < X.chunks.size() && ok && budget > 0 && (cnt0 < need0 || cnt1 < need1); ++k) {
+                    Chunk &c = X.chunks[k];
+                    if (c.in_src || c.tA >= 0.f) continue;
+                    if (!timeA(k)) break;
+                    --budget;
+                    if (c.tA > thr_slow) ++cnt0; else if (c.tA < thr_fast) ++cnt1;
+                }
             }
             // the inputs get source A's own chunks first
             if (ok) {
@@ -618,6 +712,7 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
         size_t a = 0, b = 0, c = 0;
         bool all = true;
         const bool spread = !poolC.empty();
+        std::vector<uint8_t> labels;              // of the chunks the current buffer pulled (igdsp_ctx::io_spare labels)
         auto pull = [&](int pool, size_t n, std::vector<hipMemGenericAllocationHandle_t> &hs) {
             for (size_t k = 0; k < n; ++k) {
                 std::vector<size_t> *p = pool == 0 ? &poolA : (pool == 1 ? &poolB : &poolC);
@@ -625,6 +720,7 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
                 if (*cur >= p->size() && pool != 0) { p = pool == 1 ? &poolC : &poolB; cur = pool == 1 ? &c : &b; }
                 if (*cur >= p->size()) return;
                 X.chunks[(*p)[*cur]].used = true;
+                labels.push_back(p == &poolA ? 0 : (p == &poolC ? 3 : (lab_split ? 2 : 1)));
                 hs.push_back(X.chunks[(*p)[(*cur)++]].h);
             }
         };
@@ -632,6 +728,7 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
             for (uint32_t i = 0; i < n_bufs && ok; ++i) {
                 if (bufs[i].role != role) continue;
                 std::vector<hipMemGenericAllocationHandle_t> hs;
+                labels.clear();
                 if (role == IGDSP_IO_INPUT) pull(0, nch[i], hs);
                 else {
                     const size_t h2 = (role == IGDSP_IO_BULK && spread) ? nch[i] / 2 : 0;  // second-half chunks from class C
@@ -642,6 +739,7 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
                 auto &m = set->maps[i];
                 ok = map_chunks(m, chunk, hs, 0, X.acc);
                 m.handles = hs;
+                m.cls = labels;
             }
         R.placed = (ok && all) ? 1u : 0u;
         R.bulk_spread = (ok && all && spread && bulk_chunks > 0) ? 1u : 0u;
@@ -690,6 +788,25 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
             X.probe_n = keep;
         }
     }
+    // Leftovers whose class the search established stay with the context as spares (up to io_spare_cap per class): the next call
+    // that they cover maps them without probing.  Pool members first (they were classified with the final thresholds), then any
+    // other timed chunk; chunks between two levels, or never timed, are released like before.
+    if (ok && want_place && R.placed && lab_fast > 0.f) {
+        for (size_t k : poolA) if (!X.chunks[k].used) X.chunks[k].cls = 0;
+        for (size_t k : poolB) if (!X.chunks[k].used) X.chunks[k].cls = lab_split ? 2 : 1;
+        for (size_t k : poolC) if (!X.chunks[k].used) X.chunks[k].cls = 3;
+        std::lock_guard<std::mutex> g(ctx->io_mu);
+        for (auto &c : X.chunks) {
+            if (c.used || c.in_src) continue;
+            if (c.cls < 0 && c.tA >= 0.f) {
+                if (c.tA > lab_slow) c.cls = 0;
+                else if (c.tA < lab_fast) c.cls = !lab_split ? 1 : (c.tB > lab_thrB ? 2 : ((c.tB >= 0.f && c.tB < lab_thrC) ? 3 : -1));
+            }
+            if (c.cls >= 0 && ctx->io_spare[c.cls].size() < ctx->io_spare_cap) { ctx->io_spare[c.cls].push_back(c.h); c.used = true; }
+        }
+    }
+    released_chunks = 0;
+    for (const auto &c : X.chunks) if (!c.used) ++released_chunks;
     X.cleanup();                                    // exploration leftovers go back before anything else is allocated
     for (uint32_t role = 0; role < 3 && ok; ++role)
         for (uint32_t i = 0; i < n_bufs && ok; ++i)

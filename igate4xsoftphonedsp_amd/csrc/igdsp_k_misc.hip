@@ -341,6 +341,47 @@ __global__ __launch_bounds__(kBlockThreads) void k_stream_mix(const uint4 *__res
     }
 }
 
+// Calibration of CLUSTERED record stores (round-3 question: does the same-class read / write penalty shrink when reads and writes
+// alternate less often?): the meter's 10 : 1 traffic, but a wave reads K consecutive super-chunks (K x 10 KiB) before it stores
+// their K record blocks as one K KiB run.  K = 1 is k_stream_rw's pattern.
+template <int K>
+__global__ __launch_bounds__(kBlockThreads) void k_stream_cluster(const uint4 *__restrict__ src, uint32_t n_super, uint4 *__restrict__ dst)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_items = n_super / (uint32_t)K;
+    for (uint32_t b = blockIdx.x; b * kWavesPerBlock + wave < n_items; b += gridDim.x) {
+        const uint32_t item = b * kWavesPerBlock + wave;
+        uint4 acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint4 *p = src + (((uint64_t)item * (uint32_t)K + (uint32_t)k) * 640u + lane);
+            uint4 v[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) v[j] = ld_stream(p + j * 64);
+            acc[k] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 10; ++j) { acc[k].x ^= v[j].x; acc[k].y ^= v[j].y; acc[k].z ^= v[j].z; acc[k].w ^= v[j].w; }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) dst[((uint64_t)item * (uint32_t)K + (uint32_t)k) * 64u + lane] = acc[k];
+    }
+}
+
+hipError_t launch_stream_cluster(const LaunchCfg &cfg, const void *src, size_t bytes, void *dst, int k, hipStream_t s)
+{
+    const uint32_t n_super = (uint32_t)(bytes / 10240u);
+    const dim3 g(cfg.compute_units), b(kBlockThreads);
+    const uint4 *sp = reinterpret_cast<const uint4 *>(src);
+    uint4 *dp = reinterpret_cast<uint4 *>(dst);
+    if (k == 1) hipLaunchKernelGGL((k_stream_cluster<1>), g, b, 0, s, sp, n_super, dp);
+    else if (k == 2) hipLaunchKernelGGL((k_stream_cluster<2>), g, b, 0, s, sp, n_super, dp);
+    else if (k == 4) hipLaunchKernelGGL((k_stream_cluster<4>), g, b, 0, s, sp, n_super, dp);
+    else if (k == 8) hipLaunchKernelGGL((k_stream_cluster<8>), g, b, 0, s, sp, n_super, dp);
+    else if (k == 16) hipLaunchKernelGGL((k_stream_cluster<16>), g, b, 0, s, sp, n_super, dp);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 hipError_t launch_gen_uniform(uint8_t *out, uint64_t n_bytes, uint64_t seed, uint64_t first_byte, hipStream_t s)
 {
     if (n_bytes == 0) return hipSuccess;

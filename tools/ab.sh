@@ -1,6 +1,9 @@
 #!/bin/bash
-# A/B: rebuild with -D flags on the box and bench each (the diagnostic IGDSP_AB_* knobs — builds whose RESULTS ARE WRONG —
-# live in tools/ab_knobs.patch: `git apply tools/ab_knobs.patch` first, `git apply -R` after); usage: tools/ab.sh "<flags A>" "<flags B>" ...  (bench args via BENCH_ARGS)
+# A/B: rebuild with -D flags on the box and bench each; usage: tools/ab.sh "<flags A>" "<flags B>" ...  (bench args via BENCH_ARGS).
+# The knobs are the #ifdef / #ifndef switches the kernel sources carry themselves: -DIGDSP_NT_STORE=1, -DIGDSP_NO_SPREAD,
+# -DIGDSP_SPREAD_METER=1, -DIGDSP_RT_WAVES=N, -DIGDSP_RTL_WAVES=N, and, for the fused window kernel, -DIGDSP_WIN_NOBOOK /
+# -DIGDSP_WIN_ASC (those two produce WRONG windows on purpose: what the kernel's time does not depend on).  (Round 1's
+# wrong-result IGDSP_AB_* knobs lived in a patch against a file that no longer exists; they are in git history.)
 for fl in "$@"; do
   IGDSP_CXXFLAGS="$fl" python3 -m igate4xsoftphonedsp_amd.build --force > /dev/null 2>&1 || { echo "build failed: $fl"; continue; }
   for i in 1 2; do
