@@ -61,15 +61,24 @@ def _compile_all(objdir: str, extra: list[str], verbose: bool, cwd: str) -> list
         return list(ex.map(run, jobs))
 
 
+# what the last build() call did: translation units compiled vs libraries found up to date (the driver's "does it build" check reads
+# this through __graft_entry__.build(): a reused library and a fresh compile must not look the same)
+LAST = {"device_compiled": 0, "device_reused": 0, "host_compiled": 0, "host_reused": 0}
+
+
 def build(force: bool = False, save_asm: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in DEVICE_SOURCES]
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    LAST.update(device_compiled=0, device_reused=0, host_compiled=0, host_reused=0)
     if force or _stale(LIB, deps):
         objs = _compile_all(os.path.join(PKG, "_obj"), [], verbose, PKG)
         link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         if verbose:
             print(" ".join(link))
         subprocess.run(link, check=True, cwd=PKG)
+        LAST["device_compiled"] = len(objs)
+    else:
+        LAST["device_reused"] = len(DEVICE_SOURCES)
     if save_asm:   # a pass of its own: keeps every translation unit's .s (and the resource remarks) under _asm/
         asm_dir = os.path.join(PKG, "_asm")
         _compile_all(asm_dir, ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"], verbose, asm_dir)
@@ -84,9 +93,12 @@ def build(force: bool = False, save_asm: bool = False, verbose: bool = False) ->
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True, cwd=PKG)
+            LAST["host_compiled"] = len(host_srcs)
+        else:
+            LAST["host_reused"] = len(host_srcs)
     return LIB
 
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, save_asm="--asm" in sys.argv, verbose=True)
-    print("built", LIB)
+    print("built", LIB, LAST)

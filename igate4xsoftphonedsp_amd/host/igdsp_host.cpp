@@ -78,6 +78,10 @@ int RoIP_ED137::bindRadio(int slot, int call_id)
 void RoIP_ED137::setIncomingRTP(tp_adapter *adapter)
 {
     if (!adapter || inviteMode != SERVER) return;
+    // the frame is staged under the adapter's current ED-137 word — what get_ed137_value(tp) would return at this moment
+    // (ntohl(adapter->ed137_value), TransportAdapter.cpp:337-346): the flush gates the frame's fold into the call's window with it
+    // when a gate mode is set (igdsp_set_gate_mode; PTT / SQU masks Functions.cpp:1136, 1160)
+    (void)igdsp_set_ed137(ctx_, rx_key(adapter->callID), ntohl(adapter->ed137_value));
     (void)igdsp_on_rtp_frame(ctx_, rx_key(adapter->callID), adapter->last_rx_pt, adapter->payload_buff,
                              (uint32_t)adapter->payload_bufSize);
 }

@@ -269,3 +269,42 @@ def test_wav_expand_on_device_equals_real_wavwriter(orc, golden_dir, tmp_path):
         assert ctx.L.igdsp_wav_expand(ctx.h, None, 4, 4, 160, 8000, p, 4096, None) == -22
     finally:
         ctx.close()
+
+
+def test_rx_window_gated_by_the_squelch_bit_through_the_host_mirror(host, orc):
+    """RTP packets -> transport_rtp_cb -> setIncomingRTP (which stages the frame under ntohl(adapter->ed137_value), what
+    get_ed137_value would return, TransportAdapter.cpp:337-346) -> flush with the gate mode set to SQU: only frames whose ED-137
+    word has the squelch bit (0x10000000, Functions.cpp:1160) reach the call's window; the consecutive-silence run follows all."""
+    L, h = host
+    L.igdsp_host_ctx.restype = C.c_void_p
+    L.igdsp_host_ctx.argtypes = [C.c_void_p]
+    ctxp = L.igdsp_host_ctx(h)
+    lib = capi.load()
+    assert lib.igdsp_set_gate_mode(ctxp, capi.GATE_SQU) == 0
+    cid, slot = 21, 0
+    ad = L.igdsp_host_adapter_new(cid, 1)
+    assert L.igdsp_host_bind_radio(h, slot, cid) == 0
+    rng = np.random.default_rng(8)
+    hold, probe = orc.hold_new(1), np.zeros(1, orc.CHAN_PROBE)
+    n_done = C.c_uint32()
+    for f in range(60):
+        squ = int(rng.integers(0, 2))
+        word = (squ << 28) | (int(rng.integers(0, 8)) << 29) | int(rng.integers(0, 1 << 20))
+        body = bytes([0xD5]) * 160 if rng.integers(0, 2) else orc.gen_uniform(160, seed=f).tobytes()
+        pkt = hu.rtp_packet(8, f, body, radio=True, ed137_word=word)
+        L.transport_rtp_cb(ad, pkt, len(pkt))
+        est = orc.decode_meter(np.frombuffer(body, np.uint8).reshape(1, 1, 160), [8])
+        info = np.zeros((1, 1), orc.RTP_INFO)
+        info["ed137"], info["payload_len"] = word, 160
+        orc.window_update(est, hold, info=info, gate_mode=orc.GATE_SQU, probe=probe)
+        if f % 2:
+            assert L.igdsp_host_tick(h, C.byref(n_done)) == 0 and n_done.value == 2
+    hg = np.zeros((), capi.CHAN_HOLD)
+    assert lib.igdsp_get_hold(ctxp, 2 * slot, hg.ctypes.data_as(C.c_void_p)) == 0
+    for fld in capi.CHAN_HOLD.names:
+        assert int(hg[fld]) == int(hold[fld][0]), fld
+    pr = capi.ChanProbe()
+    assert lib.igdsp_get_probe(ctxp, 2 * slot, C.byref(pr)) == 0
+    assert (pr.run, pr.alarms) == (int(probe["run"][0]), int(probe["alarms"][0]))
+    assert 0 < int(hold["count"][0]) < 60
+    L.igdsp_host_adapter_free(ad)
