@@ -957,6 +957,108 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
               a_bm, a_peak, u_frames, u_sil, u_clip);
 }
 
+// ============================================================================
+// Tiny frames — k_meter_tiny<N4>: dense frames of n = 4 N4 bytes, N4 = 4 .. 8 (16 .. 32 bytes: the 24-byte payload the hook
+// anticipates, roip_ed137.cpp:6562, and its neighbours), records only.  At these sizes a frame is smaller than two 16-byte
+// pieces, so the piece / strip machinery of k_meter_strided spends most of its instructions on bookkeeping (two wave-wide loads,
+// a strip round trip and a tail hand-over per 1.5 KiB item: 0.60 of peak at n = 24).  Here a LANE owns a FRAME outright: it loads
+// its own n bytes (one dword-aligned 16-byte load + the rest), expands them through the 4-byte m * m table (fill_lut32: one
+// ds_read_b32 per sample, the law is one bit of the lane's table offset), keeps sum / max / byte-sum in three registers — 32
+// samples x 2^26 still fit 32 bits — and stores its 16-byte record: 64 lanes = one 1 KiB store, no LDS hand-off at all.  No frame
+// is long enough for the silence probe (bytes 28 / 38 / 48 need n > 48).  Items of 64 frames; a queue slot stands for kTinySlot
+// consecutive items; kTinyDepth items of loads stay in flight per wave across slot boundaries.
+// ============================================================================
+constexpr int kTinyWaves = 16, kTinyDepth = 4;
+constexpr uint32_t kTinySlot = 16;
+
+template <int N4, bool AGG>
+__global__ __launch_bounds__(kTinyWaves * 64) void k_meter_tiny(
+    const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t n_frames,
+    igdsp_frame_stats *__restrict__ stats, igdsp_aggregate *agg, uint32_t rank, uint32_t *gqueue)
+{
+    static_assert(N4 >= 4 && N4 <= 8, "16 .. 32-byte frames");
+    constexpr uint32_t n = 4u * N4;
+    __shared__ uint32_t l32[kLut32Words];
+    __shared__ BlockQueue<kTinyWaves> bq;
+    __shared__ AggBlock aggb;
+    uint32_t gb1 = 0;
+    if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);
+    fill_lut32(l32);
+    if (threadIdx.x == 0) { bq_init(bq, gqueue, gridDim.x, gb1); agg_block_init(aggb); }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t G = gridDim.x;
+    const uint32_t n_items = n_frames / kSuperFrames;            // the launcher hands over whole items only
+    const uint32_t n_slots = (n_items + kTinySlot - 1u) / kTinySlot;
+    const uint32_t off = (lane & 31u) * 4u;
+    uint64_t a_sumsq = 0;
+    uint32_t a_bm = 0, a_peak = 0, u_frames = 0, u_sil = 0, u_clip = 0;
+
+    // the wave's item stream: slot ids from the block / device queue, kTinySlot consecutive items per slot (0xFFFFFFFF: none left)
+    uint32_t g_slot = blockIdx.x * (uint32_t)kTinyWaves + wave, g_k = 0;      // first slot static (batch = blockIdx, slot = wave)
+    if (g_slot >= n_slots) g_slot = 0xFFFFFFFFu;
+    auto next_item = [&]() -> uint32_t {
+        if (g_slot == 0xFFFFFFFFu) return 0xFFFFFFFFu;
+        if (g_k == kTinySlot) {
+            g_slot = bq_grab(bq, gqueue, G, lane, 0u);
+            g_k = 0;
+            if (g_slot >= n_slots) { g_slot = 0xFFFFFFFFu; return 0xFFFFFFFFu; }
+        }
+        const uint32_t it = g_slot * kTinySlot + g_k++;
+        if (it >= n_items) { g_slot = 0xFFFFFFFFu; return 0xFFFFFFFFu; }       // the last slot may be short
+        return it;
+    };
+    struct Item { uint4 a; uint32_t b[N4 > 4 ? N4 - 4 : 1]; uint32_t pt; };
+    auto fetch = [&](uint32_t it, Item &x) {                     // it == none: item 0 again (L2-hot), so that no load is conditional
+        const uint32_t fi = (it == 0xFFFFFFFFu ? 0u : it) * (uint32_t)kSuperFrames + lane;
+        const uint8_t *p = payload + (uint64_t)fi * n;
+        x.a = ld16_dw(p);
+#pragma unroll
+        for (int k = 4; k < N4; ++k) x.b[k - 4] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p) + k);
+        x.pt = codec[fi % C];
+    };
+    Item q[kTinyDepth];
+    uint32_t ids[kTinyDepth];
+#pragma unroll
+    for (int d = 0; d < kTinyDepth; ++d) { ids[d] = next_item(); fetch(ids[d], q[d]); }
+    auto step = [&](Item &slot, uint32_t &id) __attribute__((always_inline)) -> bool {
+        const uint32_t it = id;
+        if (it == 0xFFFFFFFFu) return false;                     // ids are handed out in order: the first missing one ends the stream
+        const Item x = slot;
+        id = next_item();
+        fetch(id, slot);                                         // the register set is free again: kTinyDepth items ahead
+        const bool alaw = x.pt == IGDSP_PT_PCMA;
+        const uint32_t oj = off | (alaw ? 0x80u : 0u);
+        uint32_t sum = 0, mx = 0, bsum = 0;
+        auto dword = [&](uint32_t w) {
+            const uint32_t q0 = lut32_at(l32, w, oj, 0x0C0C0400u), q1 = lut32_at(l32, w, oj, 0x0C0C0500u);
+            const uint32_t q2 = lut32_at(l32, w, oj, 0x0C0C0600u), q3 = lut32_at(l32, w, oj, 0x0C0C0700u);
+            sum = sum + q0 + q1; sum = sum + q2 + q3;
+            mx = max(max(mx, q0), q1); mx = max(max(mx, q2), q3);
+            bsum = __builtin_amdgcn_sad_u8(w, 0u, bsum);
+        };
+        dword(x.a.x); dword(x.a.y); dword(x.a.z); dword(x.a.w);
+#pragma unroll
+        for (int k = 4; k < N4; ++k) dword(x.b[k - 4]);
+        const uint32_t peak = isqrt_m2(mx) << 2;
+        uint32_t bm, fl;
+        st_stream(reinterpret_cast<uint4 *>(stats + ((uint64_t)it * (uint32_t)kSuperFrames + lane)),
+                  pack_stats((uint64_t)sum << 4, peak, bsum, n, alaw, false, bm, fl));
+        if (AGG) {
+            a_sumsq += (uint64_t)sum << 4; a_bm += bm; a_peak = max(a_peak, peak);
+            u_frames += (uint32_t)kSuperFrames;
+            u_sil += (uint32_t)__builtin_popcountll(__ballot((fl & IGDSP_FLAG_SILENT) != 0u));
+            u_clip += (uint32_t)__builtin_popcountll(__ballot((fl & IGDSP_FLAG_CLIPPED) != 0u));
+        }
+        return true;
+    };
+    static_assert(kTinyDepth == 4, "the loop below names the four register sets");
+    while (step(q[0], ids[0]) && step(q[1], ids[1]) && step(q[2], ids[2]) && step(q[3], ids[3])) {}
+    wave_exit(AGG ? agg : nullptr, rank, aggb, (uint32_t)kTinyWaves, lane, gqueue, G, a_sumsq, lane == 0u ? (uint64_t)u_frames * n : 0ull,
+              a_bm, a_peak, u_frames, u_sil, u_clip);
+}
+
 // Kernel attributes are per DEVICE: k_meter_image asks for more than 64 KiB of dynamic LDS (its frame images), which every device
 // that runs it has to be told once.  igdsp_create calls this with its device current (round 2 kept one flag per process, so in a
 // process with one context per GPU every device after the first would have had its image launches rejected).
@@ -1011,6 +1113,22 @@ hipError_t launch_decode_meter(const LaunchCfg &cfg, int variant, const uint8_t 
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
+    }
+    // 16 .. 32-byte frames, records only: a lane per frame (k_meter_tiny)
+    if (done == 0 && variant != 1 && len == nullptr && pcm == nullptr && (n & 3u) == 0u && n >= 16u && n <= 32u && n_frames >= (uint32_t)kSuperFrames &&
+        ((reinterpret_cast<uintptr_t>(payload) & 3u) == 0u) && ((reinterpret_cast<uintptr_t>(stats) & 15u) == 0u) && std::getenv("IGDSP_NO_TINY") == nullptr) {
+        const uint32_t n_items = n_frames / kSuperFrames;
+        const uint32_t whole = n_items * kSuperFrames;
+        const uint32_t grid = blocks_for((n_items + kTinySlot - 1u) / kTinySlot, kTinyWaves, (uint32_t)cfg.compute_units);
+#define IGDSP_TINY(NV)                                                                                                                              \
+        if ((n >> 2) == NV) {                                                                                                                        \
+            if (agg) hipLaunchKernelGGL((k_meter_tiny<NV, true>), dim3(grid), dim3(kTinyWaves * 64), 0, s, payload, codec, C, whole, stats, agg, rank, gq);   \
+            else     hipLaunchKernelGGL((k_meter_tiny<NV, false>), dim3(grid), dim3(kTinyWaves * 64), 0, s, payload, codec, C, whole, stats, agg, rank, gq);  \
+            done = whole;                                                                                                                            \
+        }
+        IGDSP_TINY(4) IGDSP_TINY(5) IGDSP_TINY(6) IGDSP_TINY(7) IGDSP_TINY(8)
+#undef IGDSP_TINY
+        if (done) { hipError_t e = hipGetLastError(); if (e != hipSuccess) return e; }
     }
     // dense frames of 16 Q + 4 T bytes, Q in {1, 4, 5, 6, 8, 10, 12, 15}, T <= 2 (the reference's 164 / 24 and the 5 ms multiples
     // up to 240) keep the chunk pipeline: k_meter_strided.  With PCM output: the reference's own sizes (24, 80, 164 / 168, 240).

@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-HOT = ("k_meter_chunk64", "k_meter_rtp64", "k_meter_image", "k_meter_strided", "k_meter_wave_per_frame", "k_roundtrip_lut64", "k_roundtrip_chunk64",
+HOT = ("k_meter_chunk64", "k_meter_rtp64", "k_meter_image", "k_meter_strided", "k_meter_tiny", "k_meter_wave_per_frame", "k_roundtrip_lut64", "k_roundtrip_chunk64",
        "k_roundtrip_general", "k_encode_lut16", "k_encode_v8", "k_depayload64", "k_wav_expand16", "k_flush_fold", "k_window_update", "k_window_finish")
 
 

@@ -4,8 +4,8 @@
 #   every other mode           : --kernel-trace | --pmc FETCH_SIZE | --pmc WRITE_SIZE      (separate passes: TCC has 4 slots)
 # Counters of one hardware block per pass only (tools/pmc_mode.sh explains why); every profiled run sits under a timeout.
 # Outputs land under gpurun_out/prof_<tag>/<mode>/<pass>/ ; tools/summarize_profile.py <tag> turns them into profiles/.
-tag=${1:-r02}; shift
-modes=${@:-"meter store roundtrip depayload rtp packets encode wav meter164 store164 roundtrip164"}
+tag=${1:-r03}; shift
+modes=${@:-"meter store roundtrip depayload rtp packets window encode wav meter164 store164 roundtrip164"}
 root=/root/repo/gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
 run() {  # run <mode> <pass> <rocprof args...>
@@ -31,7 +31,7 @@ for m in $modes; do
 done
 # the un-profiled lines of the same build
 python3 /root/repo/bench.py > $root/bench_meter_unprofiled.json 2> $root/bench_meter_unprofiled.err
-for m in store roundtrip depayload rtp packets encode wav; do
+for m in store roundtrip depayload rtp packets window encode wav; do
     python3 /root/repo/bench.py --mode $m --no-cpu-baseline > $root/bench_${m}_unprofiled.json 2> $root/bench_${m}_unprofiled.err
 done
 for m in meter store roundtrip; do
