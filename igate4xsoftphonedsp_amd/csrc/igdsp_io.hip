@@ -357,7 +357,7 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
     // default: 50 % of what is free; 85 % when bulk outputs want a THIRD class (the allocator tends to hand that one out last).
     // That is only the ceiling: the search stops as soon as every buffer has its chunks (typically 15-50 GB explored for a
     // two-class set), and later calls are served from the spares this one leaves behind.
-    double dflt = bulk_chunks >= 8 ? 0.85 : 0.5;
+    double dflt = bulk_chunks >= 4 ? 0.85 : 0.5;
     if (const char *e = std::getenv("IGDSP_IO_LIMIT_FRAC")) dflt = std::atof(e);
     size_t limit = explore_limit_bytes ? explore_limit_bytes : (size_t)(dflt * (double)free_b);
     limit = std::min(limit, (size_t)(0.9 * (double)free_b));
@@ -389,7 +389,7 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
     if (want_place) {
         std::lock_guard<std::mutex> g(ctx->io_mu);
         auto &S0 = ctx->io_spare[0], &S1 = ctx->io_spare[1], &S2 = ctx->io_spare[2], &S3 = ctx->io_spare[3];
-        const bool want_spread = bulk_chunks >= 8;
+        const bool want_spread = bulk_chunks >= 4;
         const size_t second = want_spread ? bulk_chunks / 2 : 0, first = rec_chunks + bulk_chunks - second;
         if (ctx->io_spare_chunk == chunk && S0.size() >= in_chunks && S1.size() + S2.size() >= first && S3.size() >= second && (!want_spread || S2.size() + S1.size() >= first)) {
             bool okf = true;
@@ -550,7 +550,7 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
             };
             // inputs: the chunks of source A themselves plus chunks that write slowly against it (the same class)
             if (in_chunks > kSrcChunks) walk(0, in_chunks - kSrcChunks, slow_A, poolA);
-            const bool want_spread = bulk_chunks >= 8 && std::getenv("IGDSP_IO_NO_SPREAD") == nullptr;   // (experiments: two classes only)
+            const bool want_spread = bulk_chunks >= 4 && std::getenv("IGDSP_IO_NO_SPREAD") == nullptr;   // (experiments: two classes only)
             // (with a bulk output the pool also has to yield source B and enough members of either class to re-seed it from)
             walk(0, want_spread ? std::max<size_t>(rec_chunks + bulk_chunks + kSrcChunks, 4 * kSrcChunks) : rec_chunks + bulk_chunks, fast_A, poolB);
 

@@ -710,12 +710,19 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
     static_assert(Q == 1 || Q >= 4, "the probe bytes 28 / 38 / 48 are taken from pieces 1 / 2 / 3");
     constexpr int QP = Q + (TAIL ? 1 : 0);
     constexpr int kStrip = kSuperFrames * QP;
-    __shared__ uint2 lds[kLutEntries + kRtlWaves * kStrip];
+    // RING (frames with a tail, n % 16 != 0): the re-encoded bytes of an item leave through a per-wave 2 KiB LDS ring as whole
+    // 1 KiB runs at 1 KiB-aligned offsets of the item's output row (64 n bytes, a multiple of 128 for every n % 4 == 0 — so the
+    // runs are whole cache lines).  Stored from the lanes' own registers a row of pieces is a contiguous ~1 KiB run too, but it
+    // starts and ends anywhere: consecutive store instructions then share a line, written in two halves at different times
+    // (round 2: 4 % more HBM traffic than the algorithm needs at n = 164, and 0.67 of peak where n = 160 runs at 0.75).
+    constexpr bool RING = TAIL;
+    __shared__ uint2 lds[kLutEntries + kRtlWaves * kStrip + (RING ? kRtlWaves * 256 : 0)];
     fill_recode_lut<VARIANT>(lds);
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint2 *strip = lds + kLutEntries + wave * kStrip;
+    uint32_t *ring = reinterpret_cast<uint32_t *>(lds + kLutEntries + kRtlWaves * kStrip + (RING ? wave * 256u : 0u));   // 512 dwords
     const uint32_t off = (lane & 31u) * 8u;
     const uint32_t T = (n - 16u * Q) >> 2;
     constexpr int kPk = (QP + 1) / 2;
@@ -768,6 +775,8 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
             const bool more = f + 1u < f_hi;
             const __amdgpu_buffer_rsrc_t rin = make_rsrc(in0 + (uint64_t)(more ? f + 1u : f) * fbytes);
             const __amdgpu_buffer_rsrc_t rout = make_rsrc_ranged(out0 + (uint64_t)f * fbytes, (uint32_t)kSuperFrames * n);   // this group's 64 frames of the row
+            uint32_t stored = 0, pend_off = 0xFFFFFFFFu;         // RING: bytes of this item's output row already stored (a multiple of 1 KiB); the run read last row
+            uint4 pend = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
             for (int j = 0; j < kPk; ++j) asm volatile("" : "+v"(pk[j]));
             {
@@ -815,11 +824,36 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
                         // the frame row's buffer range (raw buffer stores out of range are dropped by the hardware)
                         const bool tl = tail_of(j);
                         if (tl) ent = make_uint2(d[j].z, d[j].w);               // the frame's last two dwords, raw, for the frame lane
-                        buf_st(rout, tl ? 0x80000000u : pj, 0u, make_uint4(o[0], o[1], o[2], o[3]));
-                        if (TAIL) {
-                            const uint32_t to = tl ? pj + 16u - 4u * T : 0x80000000u;   // the tail's re-encoded bytes go right behind piece Q - 1
-                            if (T == 2u) { u32x2_t v; v.x = o[2]; v.y = o[3]; __builtin_amdgcn_raw_buffer_store_b64(v, rout, (int)to, 0, 0); }
-                            else __builtin_amdgcn_raw_buffer_store_b32(o[3], rout, (int)to, 0, 0);
+                        if (!RING) buf_st(rout, pj, 0u, make_uint4(o[0], o[1], o[2], o[3]));
+                        else {
+                            // this piece's bytes at their offset S of the output row (a payload piece: 16 bytes at its own offset; the
+                            // tail piece: the frame's last 4 T bytes, right behind piece Q - 1), parked in the ring dword by dword
+                            // (S is only dword aligned); then every whole KiB the row has reached goes out, 16 bytes per lane
+                            uint32_t S = tl ? pj + 16u - 4u * T : pj;
+                            asm volatile("" : "+v"(S));                  // derived per use: hoisted out of the frame loop the ring addresses of all rows cost 50 registers (and spilled)
+                            if (!tl) { ring[(S >> 2) & 511u] = o[0]; ring[((S >> 2) + 1u) & 511u] = o[1]; ring[((S >> 2) + 2u) & 511u] = o[2]; ring[((S >> 2) + 3u) & 511u] = o[3]; }
+                            else if (T == 2u) { ring[(S >> 2) & 511u] = o[2]; ring[((S >> 2) + 1u) & 511u] = o[3]; }
+                            else ring[(S >> 2) & 511u] = o[3];
+                            const uint32_t reach = (uint32_t)__builtin_amdgcn_readlane((int)(S + (tl ? 4u * T : 16u)), 63);   // end of the row's run
+                            // LDS operations of one wave execute in order, so the read below sees the dwords just parked and no wait is
+                            // needed between them — only the compiler must keep the order.  The run read in row j is stored in row j + 1
+                            // (pend): waiting for it at once would wait for every LUT read of the next unit issued before it.
+                            asm volatile("" ::: "memory");
+                            if (pend_off != 0xFFFFFFFFu) buf_st(rout, pend_off + 16u * lane, 0u, pend);
+                            pend_off = 0xFFFFFFFFu;
+                            if (reach - stored >= 1024u) {               // wave-uniform; a row adds at most 1 KiB, so at most one run is due
+                                pend = *reinterpret_cast<const uint4 *>(ring + (((stored >> 2) + 4u * lane) & 511u));
+                                pend_off = stored;
+                                stored += 1024u;
+                            }
+                            if (j == QP - 1) {                           // the item's last row: the pending run, then what is left (64 n % 1024 bytes, whole lines)
+                                if (pend_off != 0xFFFFFFFFu) buf_st(rout, pend_off + 16u * lane, 0u, pend);
+                                pend_off = 0xFFFFFFFFu;
+                                const uint32_t left = (uint32_t)kSuperFrames * n - stored;
+                                const uint4 v = *reinterpret_cast<const uint4 *>(ring + (((stored >> 2) + 4u * lane) & 511u));
+                                buf_st(rout, 16u * lane < left ? stored + 16u * lane : 0x80000000u, 0u, v);
+                            }
+                            asm volatile("" ::: "memory");
                         }
                         strip[j * 64 + lane] = ent;
                         d[j] = buf_ld_stream(rin, pj, 0u);

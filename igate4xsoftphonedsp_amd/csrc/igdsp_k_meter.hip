@@ -996,12 +996,16 @@ __global__ __launch_bounds__(kTinyWaves * 64) void k_meter_tiny(
     uint32_t a_bm = 0, a_peak = 0, u_frames = 0, u_sil = 0, u_clip = 0;
 
     // the wave's item stream: slot ids from the block / device queue, kTinySlot consecutive items per slot (0xFFFFFFFF: none left)
-    uint32_t g_slot = blockIdx.x * (uint32_t)kTinyWaves + wave, g_k = 0;      // first slot static (batch = blockIdx, slot = wave)
+    // At these sizes the records are 40 % of the traffic — the launch's BULK output — so the slot batches are visited alternately from
+    // the two halves of the launch (spread_batch): a record buffer that igdsp_io_alloc spread over two memory classes (IGDSP_IO_BULK) is
+    // then written in both at any moment (a 1 : 1 mix into one class streams at 0.66-0.68 of peak, into two at 0.78: DESIGN.md 7).
+    const uint32_t n_batches = (n_slots + (uint32_t)kTinyWaves - 1u) / (uint32_t)kTinyWaves;
+    uint32_t g_slot = spread_batch(blockIdx.x, n_batches) * (uint32_t)kTinyWaves + wave, g_k = 0;      // first slot static (batch = blockIdx, slot = wave)
     if (g_slot >= n_slots) g_slot = 0xFFFFFFFFu;
     auto next_item = [&]() -> uint32_t {
         if (g_slot == 0xFFFFFFFFu) return 0xFFFFFFFFu;
         if (g_k == kTinySlot) {
-            g_slot = bq_grab(bq, gqueue, G, lane, 0u);
+            g_slot = bq_grab(bq, gqueue, G, lane, n_batches);
             g_k = 0;
             if (g_slot >= n_slots) { g_slot = 0xFFFFFFFFu; return 0xFFFFFFFFu; }
         }
