@@ -452,10 +452,11 @@ int igdsp_dev_alloc_far(igdsp_ctx *ctx, void **d_ptr, size_t bytes, const void *
  *   IGDSP_IO_RECORD  small written outputs (igdsp_frame_stats, igdsp_rtp_info, len, hold): a class other than A;
  *   IGDSP_IO_BULK    large written outputs (PCM, re-encoded / dense payload): first half in one non-A class, second half
  *                    in the other (the kernels visit the two halves of a bulk output alternately).
- * Start-up use: synchronous, takes 0.2-10 s (the search, then report->settle_ms of waiting until the driver has finished
+ * Start-up use: synchronous, the first call takes 0.2-10 s (the search, then report->settle_ms of waiting until the driver has finished
  * clearing the memory the search gave back: launches run 1-5 % slow while it does); temporarily holds up to
- * explore_limit_bytes (0 = 60 % of the free device memory, 85 % when BULK buffers want a third class) of chunks while it searches and releases everything it does not
- * hand out.  The pointers stay valid until igdsp_io_free.  If the virtual-memory API is missing, the largest input is < 512 MiB (the probe then measures the
+ * explore_limit_bytes (0 = 50 % of the free device memory, 85 % when BULK buffers want a third class) of chunks while it searches and releases everything it does not
+ * hand out — except up to 16 spare chunks (2 GiB) per memory class, which stay with the context (as do the chunks of a set given back with igdsp_io_free): a later
+ * call that the spares cover is placed in < 100 ms without probing or waiting; igdsp_destroy gives them back (IGDSP_IO_SPARE_CHUNKS=0: keep none).  The pointers stay valid until igdsp_io_free.  If the virtual-memory API is missing, the largest input is < 512 MiB (the probe then measures the
  * Infinity Cache, and placement does not matter) or no second class is found, the buffers are still allocated and
  * report->placed is 0.  Buffer sizes are rounded up to whole chunks internally. */
 #define IGDSP_IO_INPUT   0u

@@ -8,6 +8,7 @@ ids in the other — wrong records with rc 0.  Pairs are now keyed by stream (la
 keeps > 64 launches pending on each stream behind a block of long launches and checks every record, PCM byte, re-encoded
 byte, hold window and aggregate of every job against the oracle."""
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -163,3 +164,59 @@ def test_many_streams_share_no_work_counters(orc):
             assert int(a[f]) == 3 * int(eagg[f]), f
         assert int(a["peak_slot"][0]) == int(eagg["peak_slot"][0])
     ctx.close()
+
+
+def test_flush_pool_with_concurrent_producers(orc):
+    """32 768 calls (the snapshot is shared out to the helper-thread pool from 16 384 channels on), four producer threads staging
+    frames for disjoint call ranges WHILE the owner thread runs flush_begin / flush_end in a loop: no frame may be lost, counted twice
+    or folded into the wrong call — every call's window count, level sum and sum of squares must equal what its own frames give
+    (every call stages the same known payload sequence, so the expected window is the oracle's over that sequence)."""
+    import ctypes as CT
+
+    nch, per_thread, rounds, fpc = 32768, 8192, 12, 2
+    c = capi.Context(device=0, max_channels=nch)
+    try:
+        for ch in range(nch):
+            c.map_call(ch, ch)
+        rng = np.random.default_rng(11)
+        n_pay = 64
+        pool = rng.integers(0, 256, (n_pay, 160), dtype=np.uint8)
+        buf = pool.ctypes.data_as(CT.c_void_p)
+        fn = c.L.igdsp_internal_stage_many
+        fn.restype = CT.c_int
+        fn.argtypes = [CT.c_void_p, CT.c_int32, CT.c_uint32, CT.c_uint32, CT.c_uint8, CT.c_void_p, CT.c_uint32, CT.c_uint32]
+        est = orc.decode_meter(pool.reshape(n_pay, 1, 160), [0])[:, 0]            # record of each payload of the pool
+        bad = []
+
+        def producer(t):
+            for r in range(rounds):
+                # frame f of call k in this round = pool[(f * n_calls + k) % n_pay] (igdsp_internal_stage_many's rule)
+                if fn(c.h, t * per_thread, per_thread, fpc, 0, buf, n_pay, 160) != 0:
+                    bad.append((t, r))
+                    return
+                time.sleep(0.002)
+
+        ths = [threading.Thread(target=producer, args=(t,)) for t in range(4)]
+        for t in ths:
+            t.start()
+        flushed = 0
+        while any(t.is_alive() for t in ths):
+            flushed += c.flush_begin()
+            c.poll(123)                                                       # reads the published set while the flush is open
+            assert c.flush_end(wait=True) == 0
+        for t in ths:
+            t.join()
+        flushed += c.flush()
+        assert not bad, f"staging overflowed (the owner fell more than 8 frames behind): {bad[:3]}"
+        assert flushed == nch * rounds * fpc
+        for ch in list(range(0, nch, 997)) + [nch - 1]:
+            k = ch % per_thread
+            idx = [(f * per_thread + k) % n_pay for f in range(fpc)] * rounds
+            h = c.get_hold(ch)
+            assert int(h["count"]) == rounds * fpc, ch
+            assert int(h["level_sum"]) == int(sum(int(est["byte_mean"][i]) for i in idx)), ch
+            assert int(h["sumsq_acc"]) == int(sum(int(est["sumsq"][i]) for i in idx)), ch
+            assert int(h["peak_hold"]) == max(int(est["peak"][i]) for i in idx), ch
+            assert c.poll(ch).frames == rounds * fpc and c.poll(ch).dropped == 0
+    finally:
+        c.close()
