@@ -187,7 +187,8 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     // every instruction added per item shows — a first version with 64-bit unit arithmetic and the unit's frame bounds live across
     // the loop executed twice the scalar and 10 % more vector instructions and ran 10 % slower)
     uint32_t w_next = 0, w_left = 0, w_seg = 0, w_unit = wave * G + blockIdx.x;          // next id, frames left in the unit, its segment, next unit
-    const uint32_t w_units = win.n_groups * win.n_seg, w_stride = G * (uint32_t)kRtpWaves;   // (< 2^27: the launcher)
+    const uint32_t nw = WIN ? (uint32_t)(blockDim.x >> 6) : (uint32_t)kRtpWaves;       // WIN blocks may run fewer waves than the strips allow
+    const uint32_t w_units = win.n_groups * win.n_seg, w_stride = G * nw;                // (< 2^27: the launcher)
     auto grab = [&]() -> uint32_t {
         if (!WIN) return bq_grab(bq, gqueue, G, lane, n_batches);
 #ifdef IGDSP_WIN_ASC              // A/B builds only (wrong windows on purpose): the WIN code over the ascending static item order
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
             cur_radio = nxt_radio;
         }
     }
-    wave_exit(AGG ? agg : nullptr, rank, aggb, (uint32_t)kRtpWaves, lane, gqueue, G, a_sumsq, (uint64_t)a_samp, a_bm, a_peak, u_frames, u_sil, u_clip);
+    wave_exit(AGG ? agg : nullptr, rank, aggb, nw, lane, gqueue, G, a_sumsq, (uint64_t)a_samp, a_bm, a_peak, u_frames, u_sil, u_clip);
 }
 
 // ============================================================================
@@ -566,9 +567,12 @@ hipError_t launch_decode_meter_rtp(const LaunchCfg &cfg, const uint8_t *slots, c
     // `radio`, a per-channel 20 / 12-byte header.  win: the gated window in the same pass (C % 64 == 0; launch_window_fused)
     const uint32_t n_frames = C * F;                       // caller guarantees a multiple of 64
     if (n_frames == 0) return hipSuccess;
-    const dim3 blk(kRtpWaves * 64);
+    dim3 blk(kRtpWaves * 64);
     if (win != nullptr) {
-        const uint32_t grid = blocks_for((uint64_t)win->n_groups * win->n_seg, kRtpWaves, (uint32_t)cfg.compute_units);
+        uint32_t waves = kRtpWaves;
+        if (const char *e = std::getenv("IGDSP_WIN_WAVES")) waves = (uint32_t)std::max(1, std::min((int)kRtpWaves, std::atoi(e)));   // experiments
+        blk = dim3(waves * 64);
+        const uint32_t grid = blocks_for((uint64_t)win->n_groups * win->n_seg, waves, (uint32_t)cfg.compute_units);
         uint32_t *noq = nullptr;                           // units are assigned statically (a grid apart), no device queue
         // (one instantiation per layout: without an aggregate the AGG code still runs and wave_exit drops the totals — the
         // aggregate-free packed instantiation needed 170 VGPRs and spilled)
