@@ -5,7 +5,7 @@
 # Counters of one hardware block per pass only (tools/pmc_mode.sh explains why); every profiled run sits under a timeout.
 # Outputs land under gpurun_out/prof_<tag>/<mode>/<pass>/ ; tools/summarize_profile.py <tag> turns them into profiles/.
 tag=${1:-r03}; shift
-modes=${@:-"meter store roundtrip depayload rtp packets window encode wav meter164 store164 roundtrip164"}
+modes=${@:-"meter store roundtrip depayload rtp packets window encode wav meter164 store164 roundtrip164 meter24"}
 root=/root/repo/gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
 run() {  # run <mode> <pass> <rocprof args...>
@@ -13,7 +13,7 @@ run() {  # run <mode> <pass> <rocprof args...>
     local out=$root/$mode/$pass
     mkdir -p $out
     local margs="--mode $mode"
-    case $mode in *164) margs="--mode ${mode%164} --frame-bytes 164";; esac
+    case $mode in *164) margs="--mode ${mode%164} --frame-bytes 164";; *24) margs="--mode ${mode%24} --frame-bytes 24";; esac
     timeout -k 10 200 rocprofv3 "$@" --output-format csv -d $out -- python3 /root/repo/bench.py $margs --steps 20 --warmup 3 --no-cpu-baseline --no-stream-calib --placement abi > $out.log 2>&1
     local rc=$?
     echo "$mode/$pass rc=$rc"
@@ -29,12 +29,13 @@ for m in $modes; do
         run $m sq2 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
     fi
 done
-# the un-profiled lines of the same build
-python3 /root/repo/bench.py > $root/bench_meter_unprofiled.json 2> $root/bench_meter_unprofiled.err
-for m in store roundtrip depayload rtp packets window encode wav; do
-    python3 /root/repo/bench.py --mode $m --no-cpu-baseline > $root/bench_${m}_unprofiled.json 2> $root/bench_${m}_unprofiled.err
-done
-for m in meter store roundtrip; do
-    python3 /root/repo/bench.py --mode $m --frame-bytes 164 --no-cpu-baseline > $root/bench_${m}164_unprofiled.json 2> $root/bench_${m}164_unprofiled.err
+# the un-profiled lines of the same build (only of the modes asked for)
+for m in $modes; do
+    case $m in
+        meter) python3 /root/repo/bench.py > $root/bench_meter_unprofiled.json 2> $root/bench_meter_unprofiled.err;;
+        *164)  python3 /root/repo/bench.py --mode ${m%164} --frame-bytes 164 --no-cpu-baseline > $root/bench_${m}_unprofiled.json 2> $root/bench_${m}_unprofiled.err;;
+        *24)   python3 /root/repo/bench.py --mode ${m%24} --frame-bytes 24 --no-cpu-baseline > $root/bench_${m}_unprofiled.json 2> $root/bench_${m}_unprofiled.err;;
+        *)     python3 /root/repo/bench.py --mode $m --no-cpu-baseline > $root/bench_${m}_unprofiled.json 2> $root/bench_${m}_unprofiled.err;;
+    esac
 done
 ls $root

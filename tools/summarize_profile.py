@@ -22,12 +22,12 @@ STEPS = 20                    # tools/profile.sh runs bench.py --steps 20: the L
 C_, F_ = 65536, 128
 KERNEL = {"meter": "k_meter_chunk64", "store": "k_meter_chunk64", "roundtrip": "k_roundtrip_lut64", "depayload": "k_depayload64",
           "rtp": "k_meter_rtp64", "packets": "k_meter_rtp64", "window": "k_meter_rtp64", "encode": "k_encode_lut16", "wav": "k_wav_expand16", "meter164": "k_meter_strided",
-          "store164": "k_meter_strided", "roundtrip164": "k_roundtrip_strided"}
+          "store164": "k_meter_strided", "roundtrip164": "k_roundtrip_strided", "meter24": "k_meter_tiny"}
 BPS = {"meter": (160 + 1 + 16) / 160, "store": (160 + 1 + 16 + 320) / 160, "roundtrip": (160 + 1 + 16 + 160) / 160,
        "depayload": (180 + 160 + 2 + 8) / 160, "rtp": (192 + 1 + 16 + 8) / 160, "packets": (180 + 1 + 16 + 8) / 160, "window": (180 + 1 + 16 + 8) / 160,
        "encode": (320 + 1 + 160) / 160, "wav": 480 / 160, "meter164": (164 + 1 + 16) / 164,
-       "store164": (164 + 1 + 16 + 328) / 164, "roundtrip164": (164 + 1 + 16 + 164) / 164}
-SAMPLES = {m: C_ * F_ * (164 if m.endswith("164") else 160) for m in KERNEL}
+       "store164": (164 + 1 + 16 + 328) / 164, "roundtrip164": (164 + 1 + 16 + 164) / 164, "meter24": (24 + 1 + 16) / 24}
+SAMPLES = {m: C_ * F_ * (164 if m.endswith("164") else 24 if m.endswith("24") else 160) for m in KERNEL}
 
 
 def newest(pattern):
