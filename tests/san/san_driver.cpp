@@ -37,6 +37,17 @@ static void oracle_pass()
         orc_hold_update(st.data(), C, F, n, hold.data(), gate.data());
         orc_roundtrip_peakhold(pl.data(), codec.data(), C, F, n, out.data(), st.data(), hold.data(), nullptr, 0);
         orc_roundtrip_peakhold(pl.data(), codec.data(), C, F, n, out.data(), st.data(), hold.data(), gate.data(), 1);
+        // the ED-137 gated window over the same records: every gate mode, info / len given or not, a tiny alarm length
+        std::vector<orc_rtp_info> winfo((size_t)C * F);
+        for (auto &i : winfo) { i.ed137 = rnd(); i.payload_len = (uint16_t)(rnd() % (n + 20)); i.pt = 0; i.flags = 0; }
+        std::vector<orc_chan_probe> probe(C);
+        memset(probe.data(), 0, C * sizeof(orc_chan_probe));
+        for (uint32_t mode = 0; mode < 4; ++mode) {
+            orc_window_update(st.data(), winfo.data(), nullptr, C, F, n, mode, 2, hold.data(), gate.data(), probe.data());
+            orc_window_update(st.data(), nullptr, len.data(), C, F, n, mode, 0, hold.data(), nullptr, nullptr);
+        }
+        std::vector<orc_frame_stats> slots(C);
+        acc += (unsigned)(orc_time_single_frame(pl.data(), codec.data(), C, F, n, 3, 1, slots.data()) >= 0.0) + probe[0].run;
         acc += st[0].peak + agg.frames;
     }
     for (uint32_t stride : {24u, 64u, 180u, 276u}) {
