@@ -307,6 +307,7 @@ def main():
     region = ctx.timer()                             # HIP events on the launch stream around the K timed launches
 
     NO_INFO = os.environ.get("IGDSP_BENCH_NO_INFO") == "1"       # experiments: the packet modes without the igdsp_rtp_info output
+    NO_RECORDS = os.environ.get("IGDSP_BENCH_WINDOW_ONLY") == "1"   # window mode without per-frame records / info: the windows alone
 
     def launch(agg, B):
         t = B.t
@@ -321,7 +322,8 @@ def main():
             ctx.decode_meter_packets(t["slots"], None, d_cd, C_, F_, 180, 20, t["st"], info=None if NO_INFO else t["info"], agg=agg, rank=rank, stream=hs)
         elif MODE == "window":
             win = ctx.window(t["hold"], gate_mode=capi.GATE_SQU_OR_PTT, probe=t["probe"], work=t["work"])
-            ctx.decode_meter_window(capi.PKT_PACKED, t["slots"], None, d_cd, None, C_, F_, 180, 20, t["st"], win, info=None if NO_INFO else t["info"], agg=agg, rank=rank, stream=hs)
+            ctx.decode_meter_window(capi.PKT_PACKED, t["slots"], None, d_cd, None, C_, F_, 180, 20, None if NO_RECORDS else t["st"], win,
+                                    info=None if (NO_INFO or NO_RECORDS) else t["info"], agg=agg, rank=rank, stream=hs)
         elif MODE == "depayload":
             ctx.depayload(t["pk"], None, d_radio, C_, F_, 180, n, t["dense"], t["len"], t["info"], stream=hs)
         elif MODE == "roundtrip":

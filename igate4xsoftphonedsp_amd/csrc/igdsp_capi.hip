@@ -705,8 +705,10 @@ int igdsp_decode_meter_window(igdsp_ctx *ctx, uint32_t layout, const uint8_t *d_
     if (!ctx || layout > IGDSP_PKT_MIXED) return IGDSP_EINVAL;
     if (int rc = check_window(ctx, win)) return rc;
     if ((uint64_t)C * F == 0) return IGDSP_OK;
-    if (!d_packets || !d_codec || !d_stats || rank >= IGDSP_AGG_MAX_RANKS) return IGDSP_EINVAL;
+    if (!d_packets || !d_codec || rank >= IGDSP_AGG_MAX_RANKS) return IGDSP_EINVAL;
     if (layout == IGDSP_PKT_MIXED && !d_radio) return IGDSP_EINVAL;
+    const bool fused = C % 64u == 0u && win->d_work != nullptr;
+    if (!d_stats && !fused) return fail(ctx, IGDSP_EINVAL, "decode_meter_window: d_stats may only be NULL on the fused path (n_channels % 64 == 0, d_work given)");
     if (int rc = check_shape(C, F, IGDSP_SAMPLES_PER_FRAME)) return rc;
     // the argument rules of the three fused entries
     uint32_t stride = 0, hdr = 20;
@@ -730,7 +732,7 @@ int igdsp_decode_meter_window(igdsp_ctx *ctx, uint32_t layout, const uint8_t *d_
     const uint32_t alarm = win->probe_alarm ? win->probe_alarm : IGDSP_PROBE_ALARM;
     hipStream_t s = pick(ctx, stream);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (C % 64u == 0u && win->d_work != nullptr) {
+    if (fused) {
         // channel-group-major fused kernel: the windows live in registers; at least one unit per resident wave, a segment is
         // never shorter than 8 frames nor longer than 65 535 (silent / clipped counts of a unit are 16 bits)
         igdsp::WinArgs w;

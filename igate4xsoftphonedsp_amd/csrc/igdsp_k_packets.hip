@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
                         rec = pack_stats(s << 4, peak, bsum, plen, my_alaw, pr, bm, fl);
                     }
                 }
-                st_stream(reinterpret_cast<uint4 *>(stats + fi), rec);
+                if (!WIN || stats != nullptr) st_stream(reinterpret_cast<uint4 *>(stats + fi), rec);   // (WIN: the records are optional — a host that only wants the windows)
                 if (AGG) {
                     if (metered) { a_sumsq += s << 4; a_samp += whole ? (uint32_t)kFrame : plen; a_bm += bm; a_peak = max(a_peak, peak); }
                     u_frames += (uint32_t)__builtin_popcountll(__ballot(metered));

@@ -389,7 +389,9 @@ int igdsp_window_update(igdsp_ctx *ctx, const igdsp_frame_stats *d_stats, const 
  * channel groups (a wavefront keeps 64 channels' windows and silence runs in registers over a segment of the frames; the
  * segments' summaries go through d_work and are folded in frame order by a small second kernel: integer sums / max / min,
  * bit-identical to the sequential fold); other channel counts, or d_work == NULL, run the plain fused kernel followed by
- * igdsp_window_update on the same stream; d_info has to be given then (it carries each frame's ED-137 word and length). */
+ * igdsp_window_update on the same stream; d_info has to be given then (it carries each frame's ED-137 word and length).
+ * On the fused path d_stats may be NULL: a host that only wants the windows (the PTT logger) then pays for no per-frame record
+ * at all — the launch reads the packets and writes 48 bytes per channel and segment. */
 #define IGDSP_PKT_SLOTS   0u
 #define IGDSP_PKT_PACKED  1u
 #define IGDSP_PKT_MIXED   2u

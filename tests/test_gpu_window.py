@@ -200,6 +200,32 @@ def test_fused_window_vs_two_step_route(ctx, orc, form, hdr, stride, C_, F_):
     assert gu.to_host(d_hold, capi.CHAN_HOLD).tobytes() == eh.tobytes()
 
 
+def test_fused_window_without_records(ctx, orc):
+    """d_stats == NULL on the fused path: the windows and runs alone, equal to the run that also writes the records."""
+    torch = gu.torch_cuda()
+    rng = np.random.default_rng(77)
+    C_, F_, stride = 128, 40, 180
+    radio, codec = np.ones(C_, np.uint8), np.full(C_, 8, np.uint8)
+    pk, sizes = _make_traffic(orc, rng, C_, F_, stride, radio, codec, seed=5)
+    hold0, probe0 = _start_state(rng, C_)
+    outs = []
+    for with_records in (True, False):
+        d_hold, d_probe = gu.to_dev(hold0), gu.to_dev(probe0)
+        win = ctx.window(d_hold, gate_mode=capi.GATE_PTT, probe=d_probe, work=gu.dev_zeros(ctx.window_work_bytes(C_)), probe_alarm=4)
+        d_st = gu.dev_zeros(F_ * C_ * 16, 0xEE) if with_records else None
+        ctx.decode_meter_window(capi.PKT_PACKED, gu.to_dev(pk), gu.to_dev(sizes), gu.to_dev(codec), None, C_, F_, stride, 20, d_st, win)
+        torch.cuda.synchronize()
+        outs.append((gu.to_host(d_hold, capi.CHAN_HOLD).tobytes(), gu.to_host(d_probe, capi.CHAN_PROBE).tobytes()))
+    assert outs[0] == outs[1]
+    _, _, _, _, eh, ep = _expected(orc, pk, sizes, radio, codec, capi.GATE_PTT, 4, None, hold0, probe0)
+    assert outs[1] == (eh.tobytes(), ep.tobytes())
+    # off the fused path the records are needed
+    import ctypes as C
+    w = ctx.window(gu.to_dev(hold0))
+    p = gu.dev_zeros(1 << 16).data_ptr()
+    assert ctx.L.igdsp_decode_meter_window(ctx.h, capi.PKT_PACKED, p, None, p, None, 64, 1, 180, 20, None, None, None, 0, C.byref(w), None) == -22
+
+
 def test_fused_window_argument_rules(ctx):
     d = gu.dev_zeros(1 << 16)
     p = d.data_ptr()
