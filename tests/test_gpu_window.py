@@ -200,6 +200,28 @@ def test_fused_window_vs_two_step_route(ctx, orc, form, hdr, stride, C_, F_):
     assert gu.to_host(d_hold, capi.CHAN_HOLD).tobytes() == eh.tobytes()
 
 
+@pytest.mark.parametrize("nseg", ["1", "2", "8"])
+def test_fused_window_segment_counts(ctx, orc, monkeypatch, nseg):
+    """The launcher's segment rule picks 4 at the headline shape; one segment (several units per wave in rounds: what a launch of
+    >= 262 144 channels gets), two and eight (the work buffer's limit) must fold to the same windows and runs."""
+    torch = gu.torch_cuda()
+    monkeypatch.setenv("IGDSP_WIN_NSEG", nseg)
+    rng = np.random.default_rng(int(nseg))
+    C_, F_, stride = 3200, 70, 180                     # 50 channel groups
+    radio, codec = np.ones(C_, np.uint8), np.where(np.arange(C_) % 2, 8, 0).astype(np.uint8)
+    pk, sizes = _make_traffic(orc, rng, C_, F_, stride, radio, codec, seed=int(nseg))
+    hold0, probe0 = _start_state(rng, C_)
+    d_hold, d_probe = gu.to_dev(hold0), gu.to_dev(probe0)
+    d_st, d_info = gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.dev_zeros(F_ * C_ * 8, 0xEE)
+    win = ctx.window(d_hold, gate_mode=capi.GATE_SQU_OR_PTT, probe=d_probe, work=gu.dev_zeros(ctx.window_work_bytes(C_), 0xEE), probe_alarm=3)
+    ctx.decode_meter_window(capi.PKT_PACKED, gu.to_dev(pk), gu.to_dev(sizes), gu.to_dev(codec), None, C_, F_, stride, 20, d_st, win, info=d_info)
+    torch.cuda.synchronize()
+    est, einfo, elen, metered, eh, ep = _expected(orc, pk, sizes, radio, codec, capi.GATE_SQU_OR_PTT, 3, None, hold0, probe0)
+    gu.assert_stats_equal(gu.to_host(d_st, capi.FRAME_STATS, (F_, C_))[metered].reshape(1, -1), est[metered].reshape(1, -1), n=elen[metered].reshape(1, -1))
+    assert gu.to_host(d_hold, capi.CHAN_HOLD).tobytes() == eh.tobytes()
+    assert gu.to_host(d_probe, capi.CHAN_PROBE).tobytes() == ep.tobytes()
+
+
 def test_fused_window_without_records(ctx, orc):
     """d_stats == NULL on the fused path: the windows and runs alone, equal to the run that also writes the records."""
     torch = gu.torch_cuda()
