@@ -92,6 +92,14 @@ __device__ __forceinline__ uint4 buf_ld_stream(__amdgpu_buffer_rsrc_t r, uint32_
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 2);          // aux 2 = nt
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+#ifndef IGDSP_RTS_LOAD_AUX
+#define IGDSP_RTS_LOAD_AUX 2      // A/B: cache policy of k_roundtrip_strided's dword-aligned input pieces (2 = nt, 0 = default)
+#endif
+__device__ __forceinline__ uint4 buf_ld_pieces(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, IGDSP_RTS_LOAD_AUX);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, const uint4 v)
 {
     u32x4_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;

@@ -769,7 +769,7 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
         {
             const __amdgpu_buffer_rsrc_t r0 = make_rsrc(in0 + (uint64_t)f_lo * fbytes);
 #pragma unroll
-            for (int j = 0; j < QP; ++j) d[j] = buf_ld_stream(r0, po_of(j), 0u);
+            for (int j = 0; j < QP; ++j) d[j] = buf_ld_pieces(r0, po_of(j), 0u);
         }
         for (uint32_t f = f_lo; f < f_hi; ++f) {
             const bool more = f + 1u < f_hi;
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
                             asm volatile("" ::: "memory");
                         }
                         strip[j * 64 + lane] = ent;
-                        d[j] = buf_ld_stream(rin, pj, 0u);
+                        d[j] = buf_ld_pieces(rin, pj, 0u);
                         sum = 0; peak = 0; bsum = 0;
                     }
                 }
