@@ -747,6 +747,35 @@ int igdsp_decode_meter_window(igdsp_ctx *ctx, uint32_t layout, const uint8_t *d_
         n_seg = std::max(1u, std::min(std::min(n_seg, kWinMaxSeg), std::max(1u, F / 8u)));
         if (F / n_seg > 65535u) return fail(ctx, IGDSP_ERANGE, "decode_meter_window: more than 8 x 65535 frames per launch");
         w.n_seg = n_seg;
+        // Block-owned form (the default where it fits): a block owns gpb = 4, 2 or 1 consecutive channel groups for the launch,
+        // hands their items to its waves in (frame, group) order and keeps their windows and runs in its LDS — the item-level
+        // balance of the time-major kernels inside a block, no summaries, no finish kernel.  gpb: as many groups per block as
+        // still give every CU a block; taken when the blocks fill whole rounds of the CUs to 85 % (a launch of 1.25 rounds would
+        // idle 3/8 of the chip in its second round: the register form above has no such steps).  The packed LDS counters hold
+        // 255 frames: longer launches go out as equal parts on the stream (hold / probe / the aggregate carry across them).
+        {
+            const uint32_t cus = (uint32_t)std::max(1, ctx->cus);
+            uint32_t gpb = 1u;
+            for (uint32_t g = 4u; g > 1u; g >>= 1) if (w.n_groups % g == 0u && w.n_groups / g >= cus) { gpb = g; break; }
+            if (const char *e = std::getenv("IGDSP_WIN_GPB")) { const uint32_t g = (uint32_t)std::atoi(e); if ((g == 1u || g == 2u || g == 4u) && w.n_groups % g == 0u) gpb = g; }   // tests
+            const uint32_t blocks = w.n_groups / gpb, rounds = (blocks + cus - 1u) / cus;
+            bool blk = (uint64_t)blocks * 100u >= (uint64_t)rounds * cus * 85u;
+            if (const char *e = std::getenv("IGDSP_WIN_BLK")) blk = std::atoi(e) != 0;       // experiments and tests: 0 = never, 1 = always
+            if (blk) {
+                w.gpb = gpb; w.gsh = gpb == 4u ? 2u : (gpb == 2u ? 1u : 0u);
+                w.hold = win->d_hold; w.gate = win->d_gate; w.probe = win->d_probe;
+                const uint32_t parts = (F + 254u) / 255u;
+                const uint64_t pkt_frame = (uint64_t)C * (stride ? stride : (uint32_t)IGDSP_SLOT_BYTES);
+                for (uint32_t k = 0; k < parts; ++k) {
+                    const uint32_t f0 = (uint32_t)(((uint64_t)F * k) / parts), f1 = (uint32_t)(((uint64_t)F * (k + 1u)) / parts);
+                    const uint64_t r0 = (uint64_t)f0 * C;
+                    w.F = f1 - f0;
+                    HIP_TRY(ctx, launch_decode_meter_rtp(cfg_of(ctx, s), d_packets + (uint64_t)f0 * pkt_frame, sizes ? sizes + r0 : nullptr, d_codec, C, f1 - f0, stride, hdr,
+                                                         d_stats ? d_stats + r0 : nullptr, d_info ? d_info + r0 : nullptr, d_agg, rank, s, radio, &w));
+                }
+                return IGDSP_OK;
+            }
+        }
         HIP_TRY(ctx, launch_decode_meter_rtp(cfg_of(ctx, s), d_packets, sizes, d_codec, C, F, stride, hdr, d_stats, d_info, d_agg, rank, s, radio, &w));
         HIP_TRY(ctx, launch_window_finish(w.work, C, n_seg, alarm, win->d_hold, win->d_gate, win->d_probe, s));
         return IGDSP_OK;

@@ -31,7 +31,15 @@ struct LaunchCfg {
 struct WinArgs {
     uint4 *work = nullptr;
     uint32_t gate_mask = 0, alarm = IGDSP_PROBE_ALARM, n_seg = 1, n_groups = 0, F = 0;   // gate_mask: ED-137 bits that open the frame gate (0 = always)
+    // block-owned form (gpb != 0): a block owns gpb = 1 << gsh consecutive channel groups for the launch, their windows live in its LDS
+    // and it folds them into hold / probe itself; work = uint4[n_groups / gpb][F][gpb] probe / reset masks
+    uint32_t gpb = 0, gsh = 0;
+    igdsp_chan_hold *hold = nullptr;
+    const uint8_t *gate = nullptr;
+    igdsp_chan_probe *probe = nullptr;
 };
+constexpr int kWinRing = 16;                             // frames of a group that may be folded before an earlier one is (power of two)
+constexpr int kWinBlkCh = 256;                           // channels a block can own (7 dwords of LDS each)
 constexpr uint32_t kWinMaxSeg = 8;                       // igdsp_window_work_bytes = kWinMaxSeg x C x 48
 
 hipError_t init_device_attributes();       // per-device kernel attributes; igdsp_create calls it with its device current

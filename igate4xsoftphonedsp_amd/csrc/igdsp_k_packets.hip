@@ -121,7 +121,17 @@ __device__ __forceinline__ void meter_short(const uint2 *lut, const uint32_t off
 // work[seg][k][c], which k_window_finish folds into hold[c] / probe[c] in segment order (integer sums, max, min: bit-identical
 // to the sequential fold).  The id stream of a wave carries the unit's segment
 // (bits 27-29) and a last-frame-of-unit flag (bit 31), so the load pipeline runs straight across unit boundaries.
-template <bool AGG, bool SLOT, bool MIXED = false, bool WIN = false>
+//
+// WIN == 2 (the default where the shape allows, igdsp_capi.hip): the state moves from the wave to the BLOCK.  Block b owns the
+// gpb = 4, 2 or 1 consecutive channel groups b * gpb ... for the whole launch and hands their F * gpb items to its waves one at a
+// time in (frame, group) order from an LDS counter — the item-level balance of the time-major kernels inside a block, and the
+// blocks walk the frames roughly together, so the memory system sees the time-major order too.  The windows of the block's
+// <= 256 channels live in LDS and move by LDS atomics (integer add / max / min: any order; measured free); the run is
+// order-dependent, so a group's frames commit in frame order through a 16-slot ring of probe / reset masks and a lock, the
+// holder applying every consecutive frame that is there — nobody waits.  At its end the block folds its windows into hold[c]
+// and writes probe[c] itself: no summaries, no finish kernel.  hold[c] is fetched one item before the end (a global load at the
+// block's end waits ~5 us behind the other blocks' streams).  Packed LDS counters: F <= 255 per launch (the launcher splits).
+template <bool AGG, bool SLOT, bool MIXED = false, int WIN = 0>
 __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     const uint8_t *__restrict__ slots, const uint16_t *__restrict__ sizes, const uint8_t *__restrict__ codec, uint32_t C,
     uint32_t n_frames, uint32_t stride, uint32_t hdr, igdsp_frame_stats *__restrict__ stats, igdsp_rtp_info *__restrict__ info,
@@ -132,10 +142,32 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     __shared__ __attribute__((aligned(16))) uint2 lds[kLutEntries + kRtpWaves * kRtpStrip];
     __shared__ BlockQueue<kRtpWaves> bq;
     __shared__ AggBlock aggb;
+    // WIN == 2: the windows of the block's own channels {sum of squares (2 dwords), frames | silent << 8 | clipped << 16,
+    // byte-mean sum | samples << 16, peak-hold, level max, level min} x kWinBlkCh channels, moved by LDS atomics
+    __shared__ uint32_t wst[WIN == 2 ? 7 * kWinBlkCh : 1];
+    __shared__ uint32_t w_ticket;                        // WIN == 2: order in which the waves start their last item
+    // WIN == 2: the consecutive-silence run is order-dependent and the frames of a channel are folded by different waves: a group's
+    // frames COMMIT in frame order (w_commit[j] = next frame of group j to commit), the run and the alarms of the block's channels
+    // live here between the launch's start and end
+    __shared__ uint32_t w_run[WIN == 2 ? kWinBlkCh : 1], w_alarms[WIN == 2 ? kWinBlkCh : 1], w_commit[4], w_lock[4];
+    __shared__ __attribute__((aligned(16))) uint4 w_ring[WIN == 2 ? 4 * kWinRing : 1];       // probe / reset masks of frames not yet committed
+    __shared__ uint32_t w_flag[WIN == 2 ? 4 * kWinRing : 1];                                  // frame + 1 once the slot holds that frame's masks
     uint32_t gb1 = 0;
+#ifdef IGDSP_BLK_STAMP
+    const uint64_t t_stamp0 = wall_clock64();
+#endif
     if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);
     fill_lut(lds);
-    if (threadIdx.x == 0) { bq_init(bq, gqueue, gridDim.x, gb1); agg_block_init(aggb); }
+    if (threadIdx.x == 0) { bq_init(bq, gqueue, gridDim.x, gb1); agg_block_init(aggb); if (WIN == 2) { bq.next = 0u; w_ticket = 0u; } }
+    if (WIN == 2) {
+        for (uint32_t i = threadIdx.x; i < 7u * (uint32_t)kWinBlkCh; i += blockDim.x) wst[i] = i >= 6u * (uint32_t)kWinBlkCh ? 255u : 0u;
+        if (threadIdx.x < win.gpb * 64u && win.probe != nullptr) {
+            const igdsp_chan_probe p0 = win.probe[blockIdx.x * win.gpb * 64u + threadIdx.x];
+            w_run[threadIdx.x] = p0.run; w_alarms[threadIdx.x] = p0.alarms;
+        }
+        if (threadIdx.x < 4u) { w_commit[threadIdx.x] = 0u; w_lock[threadIdx.x] = 0u; }
+        if (threadIdx.x < 4u * (uint32_t)kWinRing) w_flag[threadIdx.x] = 0u;
+    }
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     __syncthreads();
 
@@ -189,8 +221,15 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     uint32_t w_next = 0, w_left = 0, w_seg = 0, w_unit = wave * G + blockIdx.x;          // next id, frames left in the unit, its segment, next unit
     const uint32_t nw = WIN ? (uint32_t)(blockDim.x >> 6) : (uint32_t)kRtpWaves;       // WIN blocks may run fewer waves than the strips allow
     const uint32_t w_units = win.n_groups * win.n_seg, w_stride = G * nw;                // (< 2^27: the launcher)
+    const uint32_t b_items = win.F * win.gpb, b_first = blockIdx.x * win.gpb;                 // WIN == 2: the block's own items, in (frame, group) order
     auto grab = [&]() -> uint32_t {
         if (!WIN) return bq_grab(bq, gqueue, G, lane, n_batches);
+        if (WIN == 2) {
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(&bq.next, 1u);
+            v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            return v < b_items ? v : 0xFFFFFFFFu;            // item v of the block = frame v >> gsh of its group v & (gpb - 1)
+        }
 #ifdef IGDSP_WIN_ASC              // A/B builds only (wrong windows on purpose): the WIN code over the ascending static item order
         { const uint32_t id = w_unit; w_unit += w_stride; return id < n_super ? id : 0xFFFFFFFFu; }
 #endif
@@ -208,7 +247,7 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
         return id;
     };
     auto id_ok = [&](uint32_t id) { return WIN ? id != 0xFFFFFFFFu : id < n_super; };
-    auto id_sidx = [&](uint32_t id) { return WIN ? (id & 0x07FFFFFFu) : id; };
+    auto id_sidx = [&](uint32_t id) { return WIN == 2 ? (id >> win.gsh) * win.n_groups + b_first + (id & (win.gpb - 1u)) : (WIN ? (id & 0x07FFFFFFu) : id); };
     // the window of the unit under way (this lane = one channel): sum of squares, frames, byte-mean sum, samples,
     // {peak_hold | level_max << 16}, level_min, {n_silent | n_clipped << 16}; the silence run {run so far, probe frames before the
     // first reset | had-a-reset << 31, alarms after the first reset}
@@ -216,6 +255,22 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     uint32_t w_cnt = 0, w_lsum = 0, w_samp = 0, w_pm = 0, w_min = 255u, w_sc = 0;
     uint32_t r_trail = 0, r_lead = 0, r_hits = 0;
 
+    // WIN == 2: the fold at the block's end needs hold[c] / probe[c] / gate[c] of the block's channels, and a global load issued
+    // there waits ~5 us behind the other blocks' streams (measured).  So the first gpb waves to START their last item (or to find
+    // they have none) fetch one group's words each, a whole item ahead of the fold, and merge that group later.
+    igdsp_chan_hold e_hold = igdsp_chan_hold{};
+    uint32_t e_ticket = 0xFFFFFFFFu;
+    bool e_open = false;
+    auto end_prefetch = [&]() {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&w_ticket, 1u);
+        e_ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        if (e_ticket < win.gpb) {
+            const uint32_t c = (b_first + e_ticket) * 64u + lane;
+            e_hold = win.hold[c];
+            e_open = win.gate == nullptr || win.gate[c] != 0;
+        }
+    };
     uint32_t id_cur = WIN ? grab() : spread_batch(blockIdx.x, n_batches) * (uint32_t)kRtpWaves + wave;     // batch blockIdx.x, slot = wave
     uint32_t sidx = id_sidx(id_cur);
     if (id_ok(id_cur)) {
@@ -241,6 +296,7 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
         uint32_t s_next = grab();
         for (;;) {
             const bool has_next = id_ok(s_next);
+            if (WIN == 2 && !has_next) end_prefetch();            // (once: the loop ends with this item)
             const uint32_t s_load = has_next ? id_sidx(s_next) : 0u;
             const uint32_t f0 = sidx * kSuperFrames;
             const bool my_alaw = cur_pt == IGDSP_PT_PCMA;
@@ -324,7 +380,55 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
                     u_sil += (uint32_t)__builtin_popcountll(__ballot(metered && (fl & IGDSP_FLAG_SILENT) != 0u));
                     u_clip += (uint32_t)__builtin_popcountll(__ballot(metered && (fl & IGDSP_FLAG_CLIPPED) != 0u));
                 }
-                if (WIN) {
+                if (WIN == 2) {
+                    const uint32_t l = whole ? (uint32_t)kFrame : plen;
+                    const uint32_t gj = id_cur & (win.gpb - 1u), cl = gj * 64u + lane;          // this lane's channel within the block
+                    const bool fold = metered && (win.gate_mask == 0u || (ed & win.gate_mask) != 0u);
+                    if (fold) {                               // integer sums / max / min: any order
+                        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(wst) + cl, (unsigned long long)(s << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(wst + 2 * kWinBlkCh + cl, 1u | ((fl & IGDSP_FLAG_SILENT) ? 0x100u : 0u) | ((fl & IGDSP_FLAG_CLIPPED) ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(wst + 3 * kWinBlkCh + cl, bm | (l << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_max(wst + 4 * kWinBlkCh + cl, peak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_max(wst + 5 * kWinBlkCh + cl, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_min(wst + 6 * kWinBlkCh + cl, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    if (win.probe != nullptr) {
+                        // The run moves in FRAME order and the frames of a group are folded by different waves in any order.  Nobody
+                        // waits (a first version made every frame wait for its predecessor: +3 %): a wave leaves its frame's probe /
+                        // reset masks in the group's ring and then tries the group's lock; the holder applies every consecutive
+                        // frame that is there, starting at w_commit, and after unlocking looks once more — a wave that left its
+                        // masks while the lock was held did so before the unlock, so the holder sees them.
+                        const bool valid = metered && l > 48u, pr = valid && (fl & IGDSP_FLAG_PROBE_D5) != 0u, npr = valid && !pr;
+                        const uint64_t mp = __ballot(pr), mn = __ballot(npr);
+                        const uint32_t fr_no = id_cur >> win.gsh, rbase = gj * (uint32_t)kWinRing;
+                        auto ldu = [&](const uint32_t *p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); };
+                        while (ldu(&w_commit[gj]) + (uint32_t)kWinRing <= fr_no) __builtin_amdgcn_s_sleep(1);     // (the slot's previous frame: 16 frames back, never pending in practice)
+                        if (lane == 0u) {
+                            w_ring[rbase + (fr_no & (uint32_t)(kWinRing - 1))] = make_uint4((uint32_t)mp, (uint32_t)mn, (uint32_t)(mp >> 32), (uint32_t)(mn >> 32));
+                            __hip_atomic_store(&w_flag[rbase + (fr_no & (uint32_t)(kWinRing - 1))], fr_no + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        for (;;) {
+                            uint32_t got = 0;
+                            if (lane == 0u) { uint32_t exp = 0u; got = __hip_atomic_compare_exchange_strong(&w_lock[gj], &exp, 1u, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u; }
+                            if (__builtin_amdgcn_readfirstlane((int)got) == 0) break;           // the holder will see this frame
+                            uint32_t n = ldu(&w_commit[gj]);
+                            uint32_t run = w_run[cl], al = w_alarms[cl];
+                            while (ldu(&w_flag[rbase + (n & (uint32_t)(kWinRing - 1))]) == n + 1u) {
+                                const uint2 m = reinterpret_cast<const uint2 *>(&w_ring[rbase + (n & (uint32_t)(kWinRing - 1))])[lane >> 5];
+                                const uint32_t b_pr = (m.x >> (lane & 31u)) & 1u, b_npr = (m.y >> (lane & 31u)) & 1u;
+                                run = b_npr ? 0u : run + b_pr;
+                                al += (b_pr != 0u && run == win.alarm) ? 1u : 0u;
+                                n += 1u;
+                            }
+                            w_run[cl] = run; w_alarms[cl] = al;
+                            if (lane == 0u) {
+                                __hip_atomic_store(&w_commit[gj], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_store(&w_lock[gj], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                            if (ldu(&w_flag[rbase + (n & (uint32_t)(kWinRing - 1))]) != n + 1u) break;
+                        }
+                    }
+                } else if (WIN) {
 #ifndef IGDSP_WIN_NOBOOK          // A/B builds only: the walk without the per-frame bookkeeping (wrong windows on purpose)
                     // branch-free: every step is a select on the lane's own predicates
                     const uint32_t l = whole ? (uint32_t)kFrame : plen;
@@ -366,6 +470,41 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
             cur_pt = nxt_pt;
             cur_radio = nxt_radio;
         }
+    }
+    if (WIN == 2) {
+        // Every item of the block's channels has been handed out; when all waves are here they have been folded and committed.
+        // The gpb waves holding hold[c] of a group merge its window (the block owns the channel for the launch: plain
+        // read-modify-write) and write the run back.
+        if (e_ticket == 0xFFFFFFFFu) end_prefetch();           // a wave that never had an item
+        const bool mine = e_ticket < win.gpb;
+        const uint32_t tch = (mine ? e_ticket : 0u) * 64u + lane, c = b_first * 64u + tch;
+        __syncthreads();
+#ifdef IGDSP_BLK_STAMP
+        const uint64_t t_loop = wall_clock64();
+#endif
+        if (mine) {
+            if (e_open) {
+                const uint32_t wa = wst[2 * kWinBlkCh + tch], wb = wst[3 * kWinBlkCh + tch];
+                if ((wa & 0xFFu) != 0u) {
+                    igdsp_chan_hold h = e_hold;
+                    h.sumsq_acc += reinterpret_cast<const unsigned long long *>(wst)[tch]; h.count += wa & 0xFFu; h.level_sum += wb & 0xFFFFu; h.samples += wb >> 16;
+                    h.peak_hold = (uint16_t)max((uint32_t)h.peak_hold, wst[4 * kWinBlkCh + tch]);
+                    h.level_max = (uint8_t)max((uint32_t)h.level_max, wst[5 * kWinBlkCh + tch]);
+                    h.level_min = (uint8_t)min((uint32_t)h.level_min, wst[6 * kWinBlkCh + tch]);
+                    h.n_silent += (wa >> 8) & 0xFFu; h.n_clipped += (wa >> 16) & 0xFFu;
+                    win.hold[c] = h;
+                }
+            }
+            if (win.probe != nullptr) win.probe[c] = igdsp_chan_probe{w_run[tch], w_alarms[tch]};
+        }
+#ifdef IGDSP_BLK_STAMP
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            win.work[(uint64_t)gridDim.x * b_items + blockIdx.x] = make_uint4((uint32_t)t_stamp0, (uint32_t)t_loop, (uint32_t)wall_clock64(), xcc);
+        }
+#endif
     }
     wave_exit(AGG ? agg : nullptr, rank, aggb, nw, lane, gqueue, G, a_sumsq, (uint64_t)a_samp, a_bm, a_peak, u_frames, u_sil, u_clip);
 }
@@ -574,11 +713,19 @@ hipError_t launch_decode_meter_rtp(const LaunchCfg &cfg, const uint8_t *slots, c
         blk = dim3(waves * 64);
         const uint32_t grid = blocks_for((uint64_t)win->n_groups * win->n_seg, waves, (uint32_t)cfg.compute_units);
         uint32_t *noq = nullptr;                           // units are assigned statically (a grid apart), no device queue
+        if (win->gpb != 0u) {                              // block-owned channel groups: one block per gpb groups
+            blk = dim3(kRtpWaves * 64);
+            const uint32_t gridb = win->n_groups / win->gpb;
+            if (stride == 0)          hipLaunchKernelGGL((k_meter_rtp64<true, true, false, 2>), dim3(gridb), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, noq, radio, *win);
+            else if (radio != nullptr) hipLaunchKernelGGL((k_meter_rtp64<true, false, true, 2>), dim3(gridb), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, noq, radio, *win);
+            else                       hipLaunchKernelGGL((k_meter_rtp64<true, false, false, 2>), dim3(gridb), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, noq, radio, *win);
+            return hipGetLastError();
+        }
         // (one instantiation per layout: without an aggregate the AGG code still runs and wave_exit drops the totals — the
         // aggregate-free packed instantiation needed 170 VGPRs and spilled)
-        if (stride == 0)          hipLaunchKernelGGL((k_meter_rtp64<true, true, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, noq, radio, *win);
-        else if (radio != nullptr) hipLaunchKernelGGL((k_meter_rtp64<true, false, true, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, noq, radio, *win);
-        else                       hipLaunchKernelGGL((k_meter_rtp64<true, false, false, true>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, noq, radio, *win);
+        if (stride == 0)          hipLaunchKernelGGL((k_meter_rtp64<true, true, false, 1>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, noq, radio, *win);
+        else if (radio != nullptr) hipLaunchKernelGGL((k_meter_rtp64<true, false, true, 1>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, noq, radio, *win);
+        else                       hipLaunchKernelGGL((k_meter_rtp64<true, false, false, 1>), dim3(grid), blk, 0, s, slots, sizes, codec, C, n_frames, stride, hdr, stats, info, agg, rank, noq, radio, *win);
         return hipGetLastError();
     }
     const uint32_t grid = blocks_for(n_frames / kSuperFrames, kRtpWaves, (uint32_t)cfg.compute_units);

@@ -152,12 +152,15 @@ def test_window_update_vs_oracle(ctx, orc, mode):
     (capi.PKT_SLOTS, 20, 180, 64, 40), (capi.PKT_SLOTS, 20, 180, 192, 17), (capi.PKT_PACKED, 20, 180, 128, 33), (capi.PKT_PACKED, 12, 172, 64, 64),
     (capi.PKT_PACKED, 20, 200, 64, 9), (capi.PKT_MIXED, 0, 180, 128, 24), (capi.PKT_MIXED, 0, 184, 64, 80), (capi.PKT_PACKED, 20, 180, 96, 2),
     (capi.PKT_SLOTS, 20, 180, 32, 6)])
-def test_fused_window_vs_two_step_route(ctx, orc, form, hdr, stride, C_, F_):
+@pytest.mark.parametrize("blk", ["0", "1"])
+def test_fused_window_vs_two_step_route(ctx, orc, monkeypatch, form, hdr, stride, C_, F_, blk):
     """packets -> records + info + aggregate + hold[c] + probe[c] in ONE entry, for every gate mode: the records / info / aggregate
-    are byte for byte those of the ungated fused entry, hold and probe equal the oracle's fold of the two-step route.  F up to
-    80 frames splits into several segments per channel group (windows merged by atomics, runs chained through the work buffer);
-    C = 96 and 32 (not multiples of 64) take the record-wise fold behind the plain fused kernel."""
+    are byte for byte those of the ungated fused entry, hold and probe equal the oracle's fold of the two-step route.  Both fused
+    forms: blk = 0, the windows in the waves' registers (F up to 80 frames splits into several segments per channel group, runs
+    chained through the work buffer), and blk = 1, the windows in the block's LDS (up to 80 frames through the 16-slot commit
+    ring); C = 96 and 32 (not multiples of 64) take the record-wise fold behind the plain fused kernel."""
     torch = gu.torch_cuda()
+    monkeypatch.setenv("IGDSP_WIN_BLK", blk)
     rng = np.random.default_rng(form * 1000 + C_ + F_)
     radio = np.ones(C_, np.uint8) if form == capi.PKT_SLOTS else (np.full(C_, hdr == 20, np.uint8) if form == capi.PKT_PACKED else rng.integers(0, 2, C_).astype(np.uint8))
     codec = np.where(np.arange(C_) % 3 == 0, 0, 8).astype(np.uint8)          # mostly A-law: its digital silence is 0xD5
@@ -206,6 +209,7 @@ def test_fused_window_segment_counts(ctx, orc, monkeypatch, nseg):
     >= 262 144 channels gets), two and eight (the work buffer's limit) must fold to the same windows and runs."""
     torch = gu.torch_cuda()
     monkeypatch.setenv("IGDSP_WIN_NSEG", nseg)
+    monkeypatch.setenv("IGDSP_WIN_BLK", "0")
     rng = np.random.default_rng(int(nseg))
     C_, F_, stride = 3200, 70, 180                     # 50 channel groups
     radio, codec = np.ones(C_, np.uint8), np.where(np.arange(C_) % 2, 8, 0).astype(np.uint8)
@@ -222,9 +226,52 @@ def test_fused_window_segment_counts(ctx, orc, monkeypatch, nseg):
     assert gu.to_host(d_probe, capi.CHAN_PROBE).tobytes() == ep.tobytes()
 
 
-def test_fused_window_without_records(ctx, orc):
+@pytest.mark.parametrize("gpb,C_,F_,alarm", [("4", 1024, 50, 3), ("2", 384, 90, 500), ("1", 192, 300, 7), ("4", 256, 520, 2), ("2", 128, 255, 4)])
+def test_fused_window_block_form(ctx, orc, monkeypatch, gpb, C_, F_, alarm):
+    """The block-owned form at 4 / 2 / 1 channel groups per block (the launcher's own rule only leaves one group per block at
+    these sizes), launches longer than the 255 frames its packed LDS counters hold (300 -> 2 parts, 520 -> 3), runs that enter
+    the launch close to the alarm length, and the records-free mode."""
+    torch = gu.torch_cuda()
+    monkeypatch.setenv("IGDSP_WIN_BLK", "1")
+    monkeypatch.setenv("IGDSP_WIN_GPB", gpb)
+    rng = np.random.default_rng(C_ + F_)
+    stride = 180
+    radio, codec = np.ones(C_, np.uint8), np.where(np.arange(C_) % 4 == 1, 0, 8).astype(np.uint8)
+    pk, sizes = _make_traffic(orc, rng, C_, F_, stride, radio, codec, seed=C_ + F_)
+    gate = (np.arange(C_) % 5 != 2).astype(np.uint8)
+    hold0, probe0 = _start_state(rng, C_)
+    probe0["run"][::3] = max(alarm, 2) - 2                       # two probe frames from the alarm
+    est, einfo, elen, metered, eh, ep = _expected(orc, pk, sizes, radio, codec, capi.GATE_SQU_OR_PTT, alarm, gate, hold0, probe0)
+    d_st0, d_info0, d_agg0 = gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.dev_zeros(F_ * C_ * 8, 0xEE), gu.dev_zeros(capi.AGGREGATE.itemsize)
+    _run_plain(ctx, capi.PKT_PACKED, pk, sizes, codec, radio, C_, F_, stride, 20, d_st0, d_info0, d_agg0, 3)
+    torch.cuda.synchronize()
+    for with_records in (True, False):
+        d_hold, d_probe = gu.to_dev(hold0), gu.to_dev(probe0)
+        d_st, d_info, d_agg = gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.dev_zeros(F_ * C_ * 8, 0xEE), gu.dev_zeros(capi.AGGREGATE.itemsize)
+        win = ctx.window(d_hold, gate_mode=capi.GATE_SQU_OR_PTT, gate=gu.to_dev(gate), probe=d_probe, work=gu.dev_zeros(ctx.window_work_bytes(C_), 0xEE), probe_alarm=alarm)
+        ctx.decode_meter_window(capi.PKT_PACKED, gu.to_dev(pk), gu.to_dev(sizes), gu.to_dev(codec), None, C_, F_, stride, 20,
+                                d_st if with_records else None, win, info=d_info if with_records else None, agg=d_agg, rank=3)
+        torch.cuda.synchronize()
+        if with_records:
+            gst = gu.to_host(d_st, capi.FRAME_STATS, (F_, C_))
+            gu.assert_stats_equal(gst[metered].reshape(1, -1), est[metered].reshape(1, -1), n=elen[metered].reshape(1, -1))
+            assert np.all(gst[~metered]["flags"] == capi.FLAG_EMPTY)
+            assert gu.to_host(d_st, np.uint8).tobytes() == gu.to_host(d_st0, np.uint8).tobytes()
+            assert gu.to_host(d_info, np.uint8).tobytes() == gu.to_host(d_info0, np.uint8).tobytes()
+        assert gu.to_host(d_agg, np.uint8).tobytes() == gu.to_host(d_agg0, np.uint8).tobytes()        # (a launch in parts adds up to the same aggregate)
+        gh, gp = gu.to_host(d_hold, capi.CHAN_HOLD), gu.to_host(d_probe, capi.CHAN_PROBE)
+        for fld in capi.CHAN_HOLD.names:
+            assert np.array_equal(gh[fld], eh[fld]), (with_records, fld, np.argwhere(gh[fld] != eh[fld])[:4].tolist())
+        for fld in capi.CHAN_PROBE.names:
+            assert np.array_equal(gp[fld], ep[fld]), (with_records, fld, np.argwhere(gp[fld] != ep[fld])[:4].tolist())
+    assert ep["alarms"].sum() > probe0["alarms"].sum()
+
+
+@pytest.mark.parametrize("blk", ["0", "1"])
+def test_fused_window_without_records(ctx, orc, monkeypatch, blk):
     """d_stats == NULL on the fused path: the windows and runs alone, equal to the run that also writes the records."""
     torch = gu.torch_cuda()
+    monkeypatch.setenv("IGDSP_WIN_BLK", blk)
     rng = np.random.default_rng(77)
     C_, F_, stride = 128, 40, 180
     radio, codec = np.ones(C_, np.uint8), np.full(C_, 8, np.uint8)
@@ -269,11 +316,15 @@ def test_fused_window_argument_rules(ctx):
     assert ctx.window_work_bytes(65536) == 8 * 65536 * 48
 
 
-def test_fused_window_full_size_equals_two_step_on_device(ctx, orc):
+@pytest.mark.parametrize("blk", ["0", "auto"])
+def test_fused_window_full_size_equals_two_step_on_device(ctx, orc, monkeypatch, blk):
     """65 536 ch x 128 packed 180-byte packets (BASELINE configs[2]'s shape behind the depayloader): the fused window launch
-    against the plain fused launch followed by igdsp_window_update on the same device data — records, info, hold and probe byte
-    for byte — plus 2 000 sampled channels of hold / probe against the oracle's fold of the device's own records."""
+    (blk = auto: the block-owned form, 256 blocks of four groups; blk = 0: the register form) against the plain fused launch
+    followed by igdsp_window_update on the same device data — records, info, hold and probe byte for byte — plus 2 000 sampled
+    channels of hold / probe against the oracle's fold of the device's own records."""
     torch = gu.torch_cuda()
+    if blk != "auto":
+        monkeypatch.setenv("IGDSP_WIN_BLK", blk)
     C_, F_, stride = 65536, 128, 180
     rng = np.random.default_rng(9)
     d_pk = torch.empty((F_ * C_ * stride,), dtype=torch.uint8, device="cuda")
