@@ -104,6 +104,39 @@ __device__ __forceinline__ void meter_short(const uint2 *lut, const uint32_t off
     s = acc; peak = pk; bsum = bs; probe = len > 48u && fail == 0u;
 }
 
+// WIN == 2 helpers: one frame's effect on a channel's consecutive-silence run (adapter->rtpFalse, TransportAdapter.cpp:657-673), and
+// the commit of every consecutive frame whose masks are in group gj's ring, by the wave that finds the group free.
+__device__ __forceinline__ void win_step(uint32_t &run, uint32_t &al, bool pr, bool npr, uint32_t alarm)
+{
+    run = npr ? 0u : run + (pr ? 1u : 0u);
+    al += (pr && run == alarm) ? 1u : 0u;
+}
+
+__device__ __forceinline__ void win_drain(uint32_t *commit, const uint32_t *flag, const uint4 *ring, uint32_t *runs, uint32_t *alarms, uint32_t gj, uint32_t lane, uint32_t alarm)
+{
+    constexpr uint32_t kLock = 0x80000000u;
+    auto ldu = [&](const uint32_t *p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); };
+    auto slot = [&](uint32_t f) { return gj * (uint32_t)kWinRing + (f & (uint32_t)(kWinRing - 1)); };
+    uint32_t *const S = commit + gj;
+    const uint32_t cl = gj * 64u + lane;
+    uint32_t n = ldu(S);
+    bool more = (n & kLock) == 0u;                            // held: the next frame that comes this way looks again
+    while (more && ldu(&flag[slot(n)]) == n + 1u) {           // the next frame to commit is there: take the group if it is still free
+        uint32_t o = n;
+        if (lane == 0u) __hip_atomic_compare_exchange_strong(S, &o, n | kLock, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t run = runs[cl], al = alarms[cl];
+        o = (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
+        if (o != n) { more = (o & kLock) == 0u; n = o; continue; }     // somebody else moved the group on (or holds it)
+        do {
+            const uint2 m = reinterpret_cast<const uint2 *>(&ring[slot(n)])[lane >> 5];
+            win_step(run, al, ((m.x >> (lane & 31u)) & 1u) != 0u, ((m.y >> (lane & 31u)) & 1u) != 0u, alarm);
+            n += 1u;
+        } while (ldu(&flag[slot(n)]) == n + 1u);
+        runs[cl] = run; alarms[cl] = al;
+        if (lane == 0u) __hip_atomic_store(S, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
 // MIXED (packed form only): the header length is per channel, 20 bytes where radio[c] != 0 and 12 elsewhere (SIP and
 // ED-137 legs in one launch, as in the reference's process); `hdr` is then ignored.  The radio flags travel like the
 // codec ids: the frame lanes fetch them one item ahead and a ballot hands every piece its packet's bit.
@@ -149,7 +182,7 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     // WIN == 2: the consecutive-silence run is order-dependent and the frames of a channel are folded by different waves: a group's
     // frames COMMIT in frame order (w_commit[j] = next frame of group j to commit), the run and the alarms of the block's channels
     // live here between the launch's start and end
-    __shared__ uint32_t w_run[WIN == 2 ? kWinBlkCh : 1], w_alarms[WIN == 2 ? kWinBlkCh : 1], w_commit[4], w_lock[4];
+    __shared__ uint32_t w_run[WIN == 2 ? kWinBlkCh : 1], w_alarms[WIN == 2 ? kWinBlkCh : 1], w_commit[4];
     __shared__ __attribute__((aligned(16))) uint4 w_ring[WIN == 2 ? 4 * kWinRing : 1];       // probe / reset masks of frames not yet committed
     __shared__ uint32_t w_flag[WIN == 2 ? 4 * kWinRing : 1];                                  // frame + 1 once the slot holds that frame's masks
     uint32_t gb1 = 0;
@@ -165,7 +198,7 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
             const igdsp_chan_probe p0 = win.probe[blockIdx.x * win.gpb * 64u + threadIdx.x];
             w_run[threadIdx.x] = p0.run; w_alarms[threadIdx.x] = p0.alarms;
         }
-        if (threadIdx.x < 4u) { w_commit[threadIdx.x] = 0u; w_lock[threadIdx.x] = 0u; }
+        if (threadIdx.x < 4u) w_commit[threadIdx.x] = 0u;
         if (threadIdx.x < 4u * (uint32_t)kWinRing) w_flag[threadIdx.x] = 0u;
     }
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -320,6 +353,15 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
             const uint32_t s_after = has_next ? grab() : 0xFFFFFFFFu;   // its LDS round trip hides under the fold below
             wave_lds_fence();
             {
+                // WIN == 2: the try for the group's commit word and the run state go out here and come back under the fold
+                // (issued after the row reads instead, with less time holding the group: 0.2773-0.2793 ms against 0.2726-0.2765)
+                uint32_t c_seen = 0, c_run = 0, c_al = 0;
+                if (WIN == 2 && win.probe != nullptr) {
+                    const uint32_t fr_no = id_cur >> win.gsh, gj = id_cur & (win.gpb - 1u);
+                    c_seen = fr_no;
+                    if (lane == 0u) __hip_atomic_compare_exchange_strong(&w_commit[gj], &c_seen, fr_no | 0x80000000u, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    c_run = w_run[gj * 64u + lane]; c_al = w_alarms[gj * 64u + lane];    // (after the compare-and-swap in LDS order: if it took the group these are the last holder's stores)
+                }
                 const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kRtpRow);       // 112-byte rows, 16-byte aligned
                 const uint4 h = row[0];                   // {size word | 0, RTP bytes 0-3, ext profile/length, ED-137 word}
                 if (!SLOT) asm volatile("" ::"v"(h.x));     // packed: h.x is unused, and without this the row is fetched as eleven dword PAIRS starting at
@@ -392,40 +434,42 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
                         __hip_atomic_fetch_max(wst + 5 * kWinBlkCh + cl, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_fetch_min(wst + 6 * kWinBlkCh + cl, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
+#ifdef IGDSP_BLK_NORUN            // A/B builds only (wrong runs on purpose): what the commit protocol costs
+                    if (win.probe != nullptr && l == 77777u) {
+#else
                     if (win.probe != nullptr) {
+#endif
                         // The run moves in FRAME order and the frames of a group are folded by different waves in any order.  Nobody
-                        // waits (a first version made every frame wait for its predecessor: +3 %): a wave leaves its frame's probe /
-                        // reset masks in the group's ring and then tries the group's lock; the holder applies every consecutive
-                        // frame that is there, starting at w_commit, and after unlocking looks once more — a wave that left its
-                        // masks while the lock was held did so before the unlock, so the holder sees them.
+                        // waits (a first version made every frame wait for its predecessor: +3 %), and the common case has no
+                        // LDS round trip in the wave's way (with two the launch was 3 % slower: an item's time is its loads' latency).
+                        // w_commit[j] = the next frame of group j to commit, bit 31 = a wave is committing.  The compare-and-swap
+                        // issued at the top of the fold takes the group if this frame IS the next one: the frame is applied from
+                        // registers and the group released, nothing read back.  Any other wave leaves its frame's probe / reset masks
+                        // in the group's ring and then looks at the group: if it is free and its next frame is there it takes the group
+                        // and applies every consecutive frame it finds.  Frames left while a wave held the group stay until a later
+                        // frame finds the group free — that frame cannot be the group's next one, so it comes this way; what is left
+                        // when the block's items are through is applied at the block's end.
                         const bool valid = metered && l > 48u, pr = valid && (fl & IGDSP_FLAG_PROBE_D5) != 0u, npr = valid && !pr;
-                        const uint64_t mp = __ballot(pr), mn = __ballot(npr);
-                        const uint32_t fr_no = id_cur >> win.gsh, rbase = gj * (uint32_t)kWinRing;
-                        auto ldu = [&](const uint32_t *p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); };
-                        while (ldu(&w_commit[gj]) + (uint32_t)kWinRing <= fr_no) __builtin_amdgcn_s_sleep(1);     // (the slot's previous frame: 16 frames back, never pending in practice)
-                        if (lane == 0u) {
-                            w_ring[rbase + (fr_no & (uint32_t)(kWinRing - 1))] = make_uint4((uint32_t)mp, (uint32_t)mn, (uint32_t)(mp >> 32), (uint32_t)(mn >> 32));
-                            __hip_atomic_store(&w_flag[rbase + (fr_no & (uint32_t)(kWinRing - 1))], fr_no + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                        for (;;) {
-                            uint32_t got = 0;
-                            if (lane == 0u) { uint32_t exp = 0u; got = __hip_atomic_compare_exchange_strong(&w_lock[gj], &exp, 1u, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u; }
-                            if (__builtin_amdgcn_readfirstlane((int)got) == 0) break;           // the holder will see this frame
-                            uint32_t n = ldu(&w_commit[gj]);
-                            uint32_t run = w_run[cl], al = w_alarms[cl];
-                            while (ldu(&w_flag[rbase + (n & (uint32_t)(kWinRing - 1))]) == n + 1u) {
-                                const uint2 m = reinterpret_cast<const uint2 *>(&w_ring[rbase + (n & (uint32_t)(kWinRing - 1))])[lane >> 5];
-                                const uint32_t b_pr = (m.x >> (lane & 31u)) & 1u, b_npr = (m.y >> (lane & 31u)) & 1u;
-                                run = b_npr ? 0u : run + b_pr;
-                                al += (b_pr != 0u && run == win.alarm) ? 1u : 0u;
-                                n += 1u;
-                            }
+                        const uint32_t fr_no = id_cur >> win.gsh, kLock = 0x80000000u;
+                        uint32_t run = c_run, al = c_al;
+                        uint32_t seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)c_seen);
+                        if (seen == fr_no) {                 // this frame was next and the group free
+                            win_step(run, al, pr, npr, win.alarm);
                             w_run[cl] = run; w_alarms[cl] = al;
-                            if (lane == 0u) {
-                                __hip_atomic_store(&w_commit[gj], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                __hip_atomic_store(&w_lock[gj], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (lane == 0u) __hip_atomic_store(&w_commit[gj], fr_no + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else {
+                            while ((seen & ~kLock) + (uint32_t)kWinRing <= fr_no) {     // (the slot's previous frame, 16 back: never pending in practice)
+                                __builtin_amdgcn_s_sleep(1);
+                                win_drain(w_commit, w_flag, w_ring, w_run, w_alarms, gj, lane, win.alarm);
+                                seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&w_commit[gj], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
                             }
-                            if (ldu(&w_flag[rbase + (n & (uint32_t)(kWinRing - 1))]) != n + 1u) break;
+                            const uint64_t mp = __ballot(pr), mn = __ballot(npr);
+                            if (lane == 0u) {
+                                const uint32_t sl = gj * (uint32_t)kWinRing + (fr_no & (uint32_t)(kWinRing - 1));
+                                w_ring[sl] = make_uint4((uint32_t)mp, (uint32_t)mn, (uint32_t)(mp >> 32), (uint32_t)(mn >> 32));
+                                __hip_atomic_store(&w_flag[sl], fr_no + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                            win_drain(w_commit, w_flag, w_ring, w_run, w_alarms, gj, lane, win.alarm);     // (skipped when the group was seen held: +0.7 %, the rings fill)
                         }
                     }
                 } else if (WIN) {
@@ -482,6 +526,10 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
 #ifdef IGDSP_BLK_STAMP
         const uint64_t t_loop = wall_clock64();
 #endif
+        if (win.probe != nullptr) {                          // frames left in the rings while their group was held: nobody holds a group now
+            if (wave < win.gpb) win_drain(w_commit, w_flag, w_ring, w_run, w_alarms, wave, lane, win.alarm);
+            __syncthreads();
+        }
         if (mine) {
             if (e_open) {
                 const uint32_t wa = wst[2 * kWinBlkCh + tch], wb = wst[3 * kWinBlkCh + tch];
