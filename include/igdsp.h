@@ -368,8 +368,9 @@ typedef struct igdsp_window {
     const uint8_t *d_gate;        /* [C] optional per-channel window state, 0 = closed                               */
     igdsp_chan_probe *d_probe;    /* [C] optional consecutive-silence state                                          */
     void *d_work;                 /* igdsp_window_work_bytes(C) bytes of device scratch, 16-byte aligned (48 B x 8 x C): */
-                                  /* the per-segment window / run summaries of igdsp_decode_meter_window's fused kernel; */
-                                  /* not used by igdsp_window_update.  One buffer per stream that launches               */
+                                  /* igdsp_decode_meter_window's fused kernels need it (the per-segment window / run     */
+                                  /* summaries of the form that keeps the windows in registers); not used by             */
+                                  /* igdsp_window_update.  One buffer per stream that launches                           */
 } igdsp_window;
 size_t igdsp_window_work_bytes(uint32_t n_channels);
 
@@ -385,13 +386,15 @@ int igdsp_window_update(igdsp_ctx *ctx, const igdsp_frame_stats *d_stats, const 
  *   IGDSP_PKT_SLOTS  = igdsp_decode_meter_rtp            (192-byte slots; d_sizes, d_radio, pkt_stride, hdr_bytes ignored)
  *   IGDSP_PKT_PACKED = igdsp_decode_meter_packets        (pkt_stride, hdr_bytes 12 / 20, optional d_sizes; d_radio ignored)
  *   IGDSP_PKT_MIXED  = igdsp_decode_meter_packets_mixed  (pkt_stride, d_radio, optional d_sizes; hdr_bytes ignored)
- * Same argument rules and records as those entries.  With n_channels % 64 == 0 and win->d_work given the kernel walks
- * channel groups (a wavefront keeps 64 channels' windows and silence runs in registers over a segment of the frames; the
- * segments' summaries go through d_work and are folded in frame order by a small second kernel: integer sums / max / min,
- * bit-identical to the sequential fold); other channel counts, or d_work == NULL, run the plain fused kernel followed by
- * igdsp_window_update on the same stream; d_info has to be given then (it carries each frame's ED-137 word and length).
- * On the fused path d_stats may be NULL: a host that only wants the windows (the PTT logger) then pays for no per-frame record
- * at all — the launch reads the packets and writes 48 bytes per channel and segment. */
+ * Same argument rules and records as those entries.  With n_channels % 64 == 0 and win->d_work given the windows are kept on
+ * the chip during the launch, in one of two forms the library picks by shape: a workgroup owns 64 / 128 / 256 consecutive
+ * channels for the launch, keeps their windows and silence runs in its LDS and writes hold[c] / probe[c] itself (launches of
+ * more than 255 frames go out in parts on the stream); or a wavefront keeps 64 channels' windows and runs in registers over a
+ * segment of the frames, the segments' summaries go through d_work and are folded in frame order by a small second kernel.
+ * Integer sums / max / min and an in-order run either way: bit-identical to the sequential fold.  Other channel counts, or
+ * d_work == NULL, run the plain fused kernel followed by igdsp_window_update on the same stream; d_info has to be given then
+ * (it carries each frame's ED-137 word and length).  On the fused path d_stats may be NULL: a host that only wants the windows
+ * (the PTT logger) then pays for no per-frame record at all — the launch reads the packets and writes hold / probe. */
 #define IGDSP_PKT_SLOTS   0u
 #define IGDSP_PKT_PACKED  1u
 #define IGDSP_PKT_MIXED   2u
