@@ -983,9 +983,6 @@ __global__ __launch_bounds__(kTinyWaves * 64) void k_meter_tiny(
     __shared__ AggBlock aggb;
     uint32_t gb1 = 0;
     if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);
-    fill_lut32(l32);
-    if (threadIdx.x == 0) { bq_init(bq, gqueue, gridDim.x, gb1); agg_block_init(aggb); }
-    __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t G = gridDim.x;
@@ -1022,10 +1019,22 @@ __global__ __launch_bounds__(kTinyWaves * 64) void k_meter_tiny(
         for (int k = 4; k < N4; ++k) x.b[k - 4] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p) + k);
         x.pt = codec[fi % C];
     };
+    // the first kTinyDepth items of a wave come from its static first slot (kTinySlot >= kTinyDepth: no queue needed yet), so their
+    // loads go out BEFORE the table is filled: at 68 us per launch the first loads' latency is worth hiding under the fill
+    static_assert(kTinySlot >= (uint32_t)kTinyDepth, "the prologue must not touch the block queue");
     Item q[kTinyDepth];
     uint32_t ids[kTinyDepth];
+#ifndef IGDSP_TINY_LATE
 #pragma unroll
     for (int d = 0; d < kTinyDepth; ++d) { ids[d] = next_item(); fetch(ids[d], q[d]); }
+#endif
+    fill_lut32(l32);
+    if (threadIdx.x == 0) { bq_init(bq, gqueue, gridDim.x, gb1); agg_block_init(aggb); }
+    __syncthreads();
+#ifdef IGDSP_TINY_LATE            // A/B builds only: the first loads after the table fill, as before
+#pragma unroll
+    for (int d = 0; d < kTinyDepth; ++d) { ids[d] = next_item(); fetch(ids[d], q[d]); }
+#endif
     auto step = [&](Item &slot, uint32_t &id) __attribute__((always_inline)) -> bool {
         const uint32_t it = id;
         if (it == 0xFFFFFFFFu) return false;                     // ids are handed out in order: the first missing one ends the stream
