@@ -694,6 +694,139 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_lut64(
 }
 
 // ============================================================================
+// Config #5, block-owned form — k_roundtrip_blk64 (late round 3): k_roundtrip_lut64's item body under the work distribution of the
+// block-owned window kernel (k_meter_rtp64<WIN = 2>, igdsp_k_packets.hip).  Block b owns the gpb = 4 (2, 1) consecutive channel
+// groups b * gpb ... for the launch and hands their F * gpb items — one frame of one group: 10 KiB in, 10 KiB out, 1 KiB of
+// records — to its waves one at a time from an LDS counter: a wave that falls behind draws fewer items, where the static walk
+// gives every wave a fixed third of a group's frames.  The windows of the block's <= 256 channels live in LDS and move by LDS
+// atomics (integer add / max / min: exact, any order — this kernel has no order-dependent state); at its end the block folds
+// them into hold[c] itself (it owns the channels: plain read-modify-write, hold[c] fetched one item ahead as in the window
+// kernel).  Blocks with an odd index walk the frames from the middle of the launch: at any moment half the chip writes the
+// first half of the output and half the second, which is what an output spread over two memory classes (IGDSP_IO_BULK)
+// needs, as the item orders of k_roundtrip_lut64 do.
+// ============================================================================
+constexpr int kRtBlkCh = 256;                             // channels a block can own (7 dwords of LDS each)
+constexpr int kRtbWaves = 12;                             // strips for up to 12 waves; the launcher starts fewer (rtb_waves)
+constexpr int kRtsbWaves = 10;                            // the same for k_roundtrip_strided<BLK> (its strips and rings are larger)
+
+template <int VARIANT>
+__global__ __launch_bounds__(kRtbWaves * 64) void k_roundtrip_blk64(
+    const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F,
+    uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats, igdsp_chan_hold *__restrict__ hold,
+    const uint8_t *__restrict__ gate, uint32_t gpb, uint32_t gsh)
+{
+    __shared__ uint2 lds[kLutEntries + kRtbWaves * kStripEntries];
+    // {sum of squares (2 dwords), byte-mean sum, peak-hold, level max, level min, silent | clipped << 16} x kRtBlkCh channels
+    __shared__ uint32_t wst[7 * kRtBlkCh];
+    __shared__ uint32_t q_next, q_ticket;
+    fill_recode_lut<VARIANT>(lds);
+    for (uint32_t i = threadIdx.x; i < 7u * (uint32_t)kRtBlkCh; i += blockDim.x) wst[i] = (i >= 5u * (uint32_t)kRtBlkCh && i < 6u * (uint32_t)kRtBlkCh) ? 255u : 0u;
+    if (threadIdx.x == 0) { q_next = 0u; q_ticket = 0u; }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint2 *strip = lds + kLutEntries + wave * kStripEntries;
+    const uint32_t off = (lane & 31u) * 8u, voff = lane * 16u;
+    uint32_t fr5, pm5;
+    pack_piece_consts(lane, fr5, pm5);
+    const uint64_t fbytes = (uint64_t)C * kFrame;                  // bytes between two frames of one channel group
+    const uint32_t b_first = blockIdx.x * gpb, b_items = F * gpb;
+    const uint32_t f_shift = (blockIdx.x & 1u) ? F / 2u : 0u;      // odd blocks start in the middle of the launch
+    auto grab = [&]() -> uint32_t {                                // block-local item number, 0xFFFFFFFF = none left
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&q_next, 1u);
+        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        return v < b_items ? v : 0xFFFFFFFFu;
+    };
+    auto frame_of = [&](uint32_t id) { const uint32_t f = (id >> gsh) + f_shift; return f >= F ? f - F : f; };
+    auto group_of = [&](uint32_t id) { return b_first + (id & (gpb - 1u)); };
+    // hold[c] of one group, fetched by the first gpb waves to start their last item (a global load at the block's end waits ~5 us)
+    igdsp_chan_hold e_hold = igdsp_chan_hold{};
+    uint32_t e_ticket = 0xFFFFFFFFu;
+    bool e_open = false;
+    auto end_prefetch = [&]() {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&q_ticket, 1u);
+        e_ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        if (e_ticket < gpb) {
+            const uint32_t c = (b_first + e_ticket) * (uint32_t)kSuperFrames + lane;
+            e_open = gate == nullptr || gate[c] != 0;
+            if (e_open) e_hold = hold[c];
+        }
+    };
+
+    uint32_t id_cur = grab();
+    if (id_cur != 0xFFFFFFFFu) {
+        uint4 X[kLoadsPerChunk], Y[kLoadsPerChunk];
+        uint32_t cur_pt = codec[group_of(id_cur) * (uint32_t)kSuperFrames + lane];
+        {
+            const __amdgpu_buffer_rsrc_t r0 = make_rsrc(payload + (uint64_t)group_of(id_cur) * kSuperFrames * kFrame + (uint64_t)frame_of(id_cur) * fbytes);
+#pragma unroll
+            for (int j = 0; j < kLoadsPerChunk; ++j) X[j] = buf_ld_stream(r0, voff, (uint32_t)j * 1024u);
+#pragma unroll
+            for (int j = 0; j < kLoadsPerChunk; ++j) Y[j] = buf_ld_stream(r0, voff, (uint32_t)kChunkBytes + (uint32_t)j * 1024u);
+        }
+        uint32_t id_next = grab();
+        for (;;) {
+            const bool more = id_next != 0xFFFFFFFFu;              // wave-uniform; the last item re-reads itself (cache hit)
+            if (!more) end_prefetch();                            // (once: the loop ends with this item)
+            const uint32_t id_load = more ? id_next : id_cur;
+            const uint32_t cg = group_of(id_cur), f = frame_of(id_cur), c0 = cg * (uint32_t)kSuperFrames;
+            const uint32_t cg_n = group_of(id_load), f_n = frame_of(id_load);
+            const bool my_alaw = cur_pt == IGDSP_PT_PCMA;
+            const uint64_t amask = __ballot(my_alaw);
+            const uint32_t nxt_pt = codec[cg_n * (uint32_t)kSuperFrames + lane];
+            const __amdgpu_buffer_rsrc_t rin = make_rsrc(payload + (uint64_t)cg_n * kSuperFrames * kFrame + (uint64_t)f_n * fbytes);
+            const __amdgpu_buffer_rsrc_t rout = make_rsrc(out + (uint64_t)c0 * kFrame + (uint64_t)f * fbytes);
+            recode_half(lds, strip, X, (uint32_t)amask, fr5, pm5, off, lane, voff, 0u, rin, rout);
+            recode_half(lds, strip + kPiecesPerChunk, Y, (uint32_t)(amask >> 32), fr5, pm5, off, lane, voff, (uint32_t)kChunkBytes, rin, rout);
+            const uint32_t id_after = more ? grab() : 0xFFFFFFFFu;  // its LDS round trip hides under the fold below
+            wave_lds_fence();
+            {
+                const uint4 *row = reinterpret_cast<const uint4 *>(strip + lane * kPiecesPerFrame);
+                uint64_t sq = 0;
+                uint32_t peak = 0, bsum = 0, fail = 0;
+#pragma unroll
+                for (int i = 0; i < kPiecesPerFrame / 2; ++i) {
+                    const uint4 v = row[i];
+                    sq += (uint64_t)(v.x + v.z);
+                    peak = max(max(peak, v.y & 0x7FFFu), v.w & 0x7FFFu);
+                    bsum += ((v.y >> 16) & 0x7FFFu) + ((v.w >> 16) & 0x7FFFu);
+                    fail |= v.y | v.w;
+                }
+                uint32_t bm, fl;
+                const uint4 rec = pack_stats160(sq, peak, bsum, my_alaw, (fail >> 31) == 0u, bm, fl);
+                buf_st(make_rsrc(stats + ((uint64_t)f * C + c0)), voff, 0u, rec);       // 64 records = 1 KiB, lane * 16
+                const uint32_t cl = (id_cur & (gpb - 1u)) * (uint32_t)kSuperFrames + lane;
+                __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(wst) + cl, (unsigned long long)(sq << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(wst + 2 * kRtBlkCh + cl, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(wst + 3 * kRtBlkCh + cl, peak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(wst + 4 * kRtBlkCh + cl, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_min(wst + 5 * kRtBlkCh + cl, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t sc = ((fl & IGDSP_FLAG_SILENT) ? 1u : 0u) + ((fl & IGDSP_FLAG_CLIPPED) ? 0x10000u : 0u);
+                if (sc != 0u) __hip_atomic_fetch_add(wst + 6 * kRtBlkCh + cl, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            wave_lds_fence();
+            if (!more) break;
+            id_cur = id_next; id_next = id_after; cur_pt = nxt_pt;
+        }
+    }
+    if (e_ticket == 0xFFFFFFFFu) end_prefetch();                   // a wave that never had an item
+    __syncthreads();
+    if (e_ticket < gpb && e_open) {
+        const uint32_t t = e_ticket * (uint32_t)kSuperFrames + lane, c = b_first * (uint32_t)kSuperFrames + t;
+        igdsp_chan_hold g = e_hold;
+        const uint32_t sc = wst[6 * kRtBlkCh + t];
+        g.sumsq_acc += reinterpret_cast<const unsigned long long *>(wst)[t]; g.count += F; g.level_sum += wst[2 * kRtBlkCh + t]; g.samples += F * (uint32_t)kFrame;
+        g.peak_hold = (uint16_t)max((uint32_t)g.peak_hold, wst[3 * kRtBlkCh + t]);
+        g.level_max = (uint8_t)max((uint32_t)g.level_max, wst[4 * kRtBlkCh + t]);
+        g.level_min = (uint8_t)min((uint32_t)g.level_min, wst[5 * kRtBlkCh + t]);
+        g.n_silent += sc & 0xFFFFu; g.n_clipped += sc >> 16;
+        hold[c] = g;
+    }
+}
+
+// ============================================================================
 // Config #5 at the reference's other frame sizes — k_roundtrip_strided<Q, TAIL>: k_roundtrip_lut64's channel-group-major walk
 // (hold window in registers, frame segments, atomic merge) over frames of n = 16 Q + 4 T bytes with k_meter_strided's piece
 // geometry: Q + TAIL pieces per frame fetched at dword alignment through buffer instructions, the tail piece handing the
@@ -701,12 +834,16 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_lut64(
 // ============================================================================
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
-template <int Q, bool TAIL, int VARIANT>
-__global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
+// BLK (late round 3): the work distribution of k_roundtrip_blk64 — block b owns n_seg (= gpb) consecutive channel groups for the
+// launch, hands their F * gpb items to its waves one at a time, keeps the windows in LDS (integer atomics) and folds them into
+// hold[c] itself; odd blocks walk the frames from the middle of the launch.  n_seg carries gpb and order log2(gpb) then.
+template <int Q, bool TAIL, int VARIANT, bool BLK = false>
+__global__ __launch_bounds__((BLK ? kRtsbWaves : kRtlWaves) * 64) void k_roundtrip_strided(
     const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F, uint32_t n,
     uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats, igdsp_chan_hold *__restrict__ hold,
     const uint8_t *__restrict__ gate, uint32_t n_seg, uint32_t n_groups, uint32_t order)
 {
+    constexpr int kW = BLK ? kRtsbWaves : kRtlWaves;
     static_assert(Q == 1 || Q >= 4, "the probe bytes 28 / 38 / 48 are taken from pieces 1 / 2 / 3");
     constexpr int QP = Q + (TAIL ? 1 : 0);
     constexpr int kStrip = kSuperFrames * QP;
@@ -716,13 +853,19 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
     // starts and ends anywhere: consecutive store instructions then share a line, written in two halves at different times
     // (round 2: 4 % more HBM traffic than the algorithm needs at n = 164, and 0.67 of peak where n = 160 runs at 0.75).
     constexpr bool RING = TAIL;
-    __shared__ uint2 lds[kLutEntries + kRtlWaves * kStrip + (RING ? kRtlWaves * 256 : 0)];
+    __shared__ uint2 lds[kLutEntries + kW * kStrip + (RING ? kW * 256 : 0)];
+    __shared__ uint32_t wst[BLK ? 7 * kRtBlkCh : 1];           // BLK: the windows of the block's channels, as in k_roundtrip_blk64
+    __shared__ uint32_t q_next, q_ticket;
     fill_recode_lut<VARIANT>(lds);
+    if (BLK) {
+        for (uint32_t i = threadIdx.x; i < 7u * (uint32_t)kRtBlkCh; i += blockDim.x) wst[i] = (i >= 5u * (uint32_t)kRtBlkCh && i < 6u * (uint32_t)kRtBlkCh) ? 255u : 0u;
+        if (threadIdx.x == 0) { q_next = 0u; q_ticket = 0u; }
+    }
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint2 *strip = lds + kLutEntries + wave * kStrip;
-    uint32_t *ring = reinterpret_cast<uint32_t *>(lds + kLutEntries + kRtlWaves * kStrip + (RING ? wave * 256u : 0u));   // 512 dwords
+    uint32_t *ring = reinterpret_cast<uint32_t *>(lds + kLutEntries + kW * kStrip + (RING ? wave * 256u : 0u));   // 512 dwords
     const uint32_t off = (lane & 31u) * 8u;
     const uint32_t T = (n - 16u * Q) >> 2;
     constexpr int kPk = (QP + 1) / 2;
@@ -742,12 +885,211 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
     auto ps_of = [&](int j) { return __builtin_amdgcn_ubfe(pk[j >> 1], 16 * (j & 1) + 8, 5); };
     auto tail_of = [&](int j) { return TAIL && ((pk[j >> 1] >> (16 * (j & 1) + 13)) & 1u) != 0u; };
     auto po_of = [&](int j) { return po[j]; };
-    const uint32_t total_waves = gridDim.x * kRtlWaves;
+    const uint32_t total_waves = gridDim.x * kW;
     const uint64_t fbytes = (uint64_t)C * n;                       // bytes between two frames of one channel group
 
+    // one frame of one channel group: d holds its pieces, rin describes the item whose pieces refill d, acc takes the frame's figures
+    auto frame_body = [&](const uint32_t c0, const uint32_t f, const __amdgpu_buffer_rsrc_t rin, const bool my_alaw, const uint32_t am_lo,
+                          const uint32_t am_hi, uint4 (&d)[QP], auto &&acc) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rout = make_rsrc_ranged(out + (uint64_t)c0 * n + (uint64_t)f * fbytes, (uint32_t)kSuperFrames * n);   // this group's 64 frames of the row
+        uint32_t stored = 0, pend_off = 0xFFFFFFFFu;         // RING: bytes of this item's output row already stored (a multiple of 1 KiB); the run read last row
+        uint4 pend = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int j = 0; j < kPk; ++j) asm volatile("" : "+v"(pk[j]));
+        {
+            uint2 e[2][8];
+            uint32_t wa[2], wb[2];
+            auto issue = [&](int u) {
+                const int j = u >> 1, k = u & 1;
+                wa[k] = (u & 1) ? d[j].z : d[j].x;
+                wb[k] = (u & 1) ? d[j].w : d[j].y;
+                const uint32_t frj = fr_of(j);
+                const uint32_t bit = frj < 32u ? (uint32_t)__builtin_amdgcn_sbfe(am_lo, frj, 1) : (uint32_t)__builtin_amdgcn_sbfe(am_hi, frj - 32u, 1);
+                const uint32_t lmj = bit & 0x80808080u;
+                const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lmj, tb = (wb[k] & 0x7F7F7F7Fu) | lmj;
+                e[k][0] = lut_at(lds, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lds, ta, off, 0x0C0C0500u);
+                e[k][2] = lut_at(lds, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lds, ta, off, 0x0C0C0700u);
+                e[k][4] = lut_at(lds, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lds, tb, off, 0x0C0C0500u);
+                e[k][6] = lut_at(lds, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lds, tb, off, 0x0C0C0700u);
+            };
+            auto recode4 = [&](uint32_t w, const uint2 &e0, const uint2 &e1, const uint2 &e2, const uint2 &e3) {
+                const uint32_t p01 = __builtin_amdgcn_perm(e1.y, e0.y, 0x05040100u);
+                const uint32_t p23 = __builtin_amdgcn_perm(e3.y, e2.y, 0x05040100u);
+                const uint32_t sel = ((w >> 7) & 0x01010101u) | 0x06040200u;
+                return __builtin_amdgcn_perm(p23, p01, sel);
+            };
+            uint32_t sum = 0, peak = 0, bsum = 0;
+            uint32_t o[4];
+            issue(0);
+#pragma unroll
+            for (int u = 0; u < 2 * QP; ++u) {
+                const int j = u >> 1, k = u & 1;
+                if (u + 1 < 2 * QP) issue(u + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                bsum = __builtin_amdgcn_sad_u8(wa[k], 0u, bsum);
+                bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
+                sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
+                sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
+                peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
+                peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
+                o[2 * k] = recode4(wa[k], e[k][0], e[k][1], e[k][2], e[k][3]);
+                o[2 * k + 1] = recode4(wb[k], e[k][4], e[k][5], e[k][6], e[k][7]);
+                if (k == 1) {
+                    uint2 ent = make_uint2(sum, (peak >> 16) | (bsum << 16) | probe_fail(d[j], 0xFFu << ps_of(j)));
+                    const uint32_t pj = po_of(j);
+                    // no branch on the per-lane tail flag: every lane issues both stores, the one that does not apply at an offset past
+                    // the frame row's buffer range (raw buffer stores out of range are dropped by the hardware)
+                    const bool tl = tail_of(j);
+                    if (tl) ent = make_uint2(d[j].z, d[j].w);               // the frame's last two dwords, raw, for the frame lane
+                    if (!RING) buf_st(rout, pj, 0u, make_uint4(o[0], o[1], o[2], o[3]));
+                    else {
+                        // this piece's bytes at their offset S of the output row (a payload piece: 16 bytes at its own offset; the
+                        // tail piece: the frame's last 4 T bytes, right behind piece Q - 1), parked in the ring dword by dword
+                        // (S is only dword aligned); then every whole KiB the row has reached goes out, 16 bytes per lane
+                        uint32_t S = tl ? pj + 16u - 4u * T : pj;
+                        asm volatile("" : "+v"(S));                  // derived per use: hoisted out of the frame loop the ring addresses of all rows cost 50 registers (and spilled)
+                        if (!tl) { ring[(S >> 2) & 511u] = o[0]; ring[((S >> 2) + 1u) & 511u] = o[1]; ring[((S >> 2) + 2u) & 511u] = o[2]; ring[((S >> 2) + 3u) & 511u] = o[3]; }
+                        else if (T == 2u) { ring[(S >> 2) & 511u] = o[2]; ring[((S >> 2) + 1u) & 511u] = o[3]; }
+                        else ring[(S >> 2) & 511u] = o[3];
+                        const uint32_t reach = (uint32_t)__builtin_amdgcn_readlane((int)(S + (tl ? 4u * T : 16u)), 63);   // end of the row's run
+                        // LDS operations of one wave execute in order, so the read below sees the dwords just parked and no wait is
+                        // needed between them — only the compiler must keep the order.  The run read in row j is stored in row j + 1
+                        // (pend): waiting for it at once would wait for every LUT read of the next unit issued before it.
+                        asm volatile("" ::: "memory");
+                        if (pend_off != 0xFFFFFFFFu) buf_st(rout, pend_off + 16u * lane, 0u, pend);
+                        pend_off = 0xFFFFFFFFu;
+                        if (reach - stored >= 1024u) {               // wave-uniform; a row adds at most 1 KiB, so at most one run is due
+                            pend = *reinterpret_cast<const uint4 *>(ring + (((stored >> 2) + 4u * lane) & 511u));
+                            pend_off = stored;
+                            stored += 1024u;
+                        }
+                        if (j == QP - 1) {                           // the item's last row: the pending run, then what is left (64 n % 1024 bytes, whole lines)
+                            if (pend_off != 0xFFFFFFFFu) buf_st(rout, pend_off + 16u * lane, 0u, pend);
+                            pend_off = 0xFFFFFFFFu;
+                            const uint32_t left = (uint32_t)kSuperFrames * n - stored;
+                            const uint4 v = *reinterpret_cast<const uint4 *>(ring + (((stored >> 2) + 4u * lane) & 511u));
+                            buf_st(rout, 16u * lane < left ? stored + 16u * lane : 0x80000000u, 0u, v);
+                        }
+                        asm volatile("" ::: "memory");
+                    }
+                    strip[j * 64 + lane] = ent;
+                    d[j] = buf_ld_pieces(rin, pj, 0u);
+                    sum = 0; peak = 0; bsum = 0;
+                }
+            }
+        }
+        wave_lds_fence();
+        {
+            const uint2 *row = strip + lane * QP;
+            uint64_t sq = 0;
+            uint32_t peak = 0, bsum = 0, fail = 0, part = 0;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                const uint2 v = row[i];
+                part += v.x;
+                if ((i & 3) == 3 || i == Q - 1) { sq += part; part = 0; }
+                peak = max(peak, v.y & 0x7FFFu);
+                bsum += (v.y >> 16) & 0x7FFFu;
+                fail |= v.y;
+            }
+            if (TAIL) {
+                const uint2 tv = row[Q];
+                const uint32_t lm = my_alaw ? 0x80808080u : 0u;
+                const uint32_t tws[2] = {T == 2u ? tv.x : tv.y, tv.y};
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    if ((uint32_t)t < T) {
+                        const uint32_t w = tws[t], tt = (w & 0x7F7F7F7Fu) | lm;
+                        const uint2 e0 = lut_at(lds, tt, off, 0x0C0C0400u), e1 = lut_at(lds, tt, off, 0x0C0C0500u);
+                        const uint2 e2 = lut_at(lds, tt, off, 0x0C0C0600u), e3 = lut_at(lds, tt, off, 0x0C0C0700u);
+                        sq += (uint64_t)(e0.x + e1.x + e2.x + e3.x);
+                        peak = max(peak, max(max(e0.y, e1.y), max(e2.y, e3.y)) >> 16);
+                        bsum = __builtin_amdgcn_sad_u8(w, 0u, bsum);
+                    }
+            }
+            uint32_t bm, fl;
+            const uint4 rec = pack_stats(sq << 4, peak, bsum, n, my_alaw, (Q >= 4) && (fail >> 31) == 0u, bm, fl);
+            buf_st(make_rsrc(stats + ((uint64_t)f * C + c0)), lane * 16u, 0u, rec);
+            acc(sq << 4, peak, bm, fl);
+        }
+        wave_lds_fence();
+    };
+    if (BLK) {
+        const uint32_t gpb = n_seg, gsh = order, b_first = blockIdx.x * gpb, b_items = F * gpb;
+        const uint32_t f_shift = (blockIdx.x & 1u) ? F / 2u : 0u;
+        auto grab = [&]() -> uint32_t {
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(&q_next, 1u);
+            v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            return v < b_items ? v : 0xFFFFFFFFu;
+        };
+        auto frame_of = [&](uint32_t id) { const uint32_t f = (id >> gsh) + f_shift; return f >= F ? f - F : f; };
+        auto group_of = [&](uint32_t id) { return b_first + (id & (gpb - 1u)); };
+        auto in_of = [&](uint32_t id) { return make_rsrc(payload + (uint64_t)group_of(id) * kSuperFrames * n + (uint64_t)frame_of(id) * fbytes); };
+        igdsp_chan_hold e_hold = igdsp_chan_hold{};
+        uint32_t e_ticket = 0xFFFFFFFFu;
+        bool e_open = false;
+        auto end_prefetch = [&]() {                               // hold[c] of one group, fetched a whole item before the block's end
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(&q_ticket, 1u);
+            e_ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            if (e_ticket < gpb) {
+                const uint32_t c = (b_first + e_ticket) * (uint32_t)kSuperFrames + lane;
+                e_open = gate == nullptr || gate[c] != 0;
+                if (e_open) e_hold = hold[c];
+            }
+        };
+        uint32_t id_cur = grab();
+        if (id_cur != 0xFFFFFFFFu) {
+            uint4 d[QP];
+            uint32_t cur_pt = codec[group_of(id_cur) * (uint32_t)kSuperFrames + lane];
+            {
+                const __amdgpu_buffer_rsrc_t r0 = in_of(id_cur);
+#pragma unroll
+                for (int j = 0; j < QP; ++j) d[j] = buf_ld_pieces(r0, po_of(j), 0u);
+            }
+            uint32_t id_next = grab();
+            for (;;) {
+                const bool more = id_next != 0xFFFFFFFFu;          // the last item re-reads itself (cache hit)
+                if (!more) end_prefetch();
+                const uint32_t id_load = more ? id_next : id_cur;
+                const bool my_alaw = cur_pt == IGDSP_PT_PCMA;
+                const uint64_t amask = __ballot(my_alaw);
+                const uint32_t nxt_pt = codec[group_of(id_load) * (uint32_t)kSuperFrames + lane];
+                const uint32_t id_after = more ? grab() : 0xFFFFFFFFu;
+                const uint32_t cl = (id_cur & (gpb - 1u)) * (uint32_t)kSuperFrames + lane;
+                frame_body(group_of(id_cur) * (uint32_t)kSuperFrames, frame_of(id_cur), in_of(id_load), my_alaw, (uint32_t)amask, (uint32_t)(amask >> 32), d,
+                           [&](uint64_t s16, uint32_t peak, uint32_t bm, uint32_t fl) {
+                    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(wst) + cl, (unsigned long long)s16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(wst + 2 * kRtBlkCh + cl, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_max(wst + 3 * kRtBlkCh + cl, peak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_max(wst + 4 * kRtBlkCh + cl, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_min(wst + 5 * kRtBlkCh + cl, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t sc = ((fl & IGDSP_FLAG_SILENT) ? 1u : 0u) + ((fl & IGDSP_FLAG_CLIPPED) ? 0x10000u : 0u);
+                    if (sc != 0u) __hip_atomic_fetch_add(wst + 6 * kRtBlkCh + cl, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                });
+                if (!more) break;
+                id_cur = id_next; id_next = id_after; cur_pt = nxt_pt;
+            }
+        }
+        if (e_ticket == 0xFFFFFFFFu) end_prefetch();               // a wave that never had an item
+        __syncthreads();
+        if (e_ticket < gpb && e_open) {
+            const uint32_t t = e_ticket * (uint32_t)kSuperFrames + lane, c = b_first * (uint32_t)kSuperFrames + t;
+            igdsp_chan_hold g = e_hold;
+            const uint32_t sc = wst[6 * kRtBlkCh + t];
+            g.sumsq_acc += reinterpret_cast<const unsigned long long *>(wst)[t]; g.count += F; g.level_sum += wst[2 * kRtBlkCh + t]; g.samples += F * n;
+            g.peak_hold = (uint16_t)max((uint32_t)g.peak_hold, wst[3 * kRtBlkCh + t]);
+            g.level_max = (uint8_t)max((uint32_t)g.level_max, wst[4 * kRtBlkCh + t]);
+            g.level_min = (uint8_t)min((uint32_t)g.level_min, wst[5 * kRtBlkCh + t]);
+            g.n_silent += sc & 0xFFFFu; g.n_clipped += sc >> 16;
+            hold[c] = g;
+        }
+        return;
+    }
     // item order as in k_roundtrip_lut64: consecutive groups per block in the first round when the output is spread over two classes
     const uint32_t n_items = n_groups * n_seg;
-    const uint32_t near = blockIdx.x * (uint32_t)kRtlWaves + wave, apart = wave * gridDim.x + blockIdx.x;
+    const uint32_t near = blockIdx.x * (uint32_t)kW + wave, apart = wave * gridDim.x + blockIdx.x;
     for (uint32_t round = 0;; ++round) {
         const uint64_t item64 = (uint64_t)round * total_waves + ((order && round == 0u) ? near : apart);
         if (item64 >= n_items) { if ((uint64_t)round * total_waves >= n_items) break; else continue; }
@@ -763,7 +1105,6 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
         const uint64_t amask = __ballot(my_alaw);
         const uint32_t am_lo = (uint32_t)amask, am_hi = (uint32_t)(amask >> 32);
         const uint8_t *in0 = payload + (uint64_t)c0 * n;
-        uint8_t *out0 = out + (uint64_t)c0 * n;
 
         uint4 d[QP];
         {
@@ -774,131 +1115,12 @@ __global__ __launch_bounds__(kRtlWaves * 64) void k_roundtrip_strided(
         for (uint32_t f = f_lo; f < f_hi; ++f) {
             const bool more = f + 1u < f_hi;
             const __amdgpu_buffer_rsrc_t rin = make_rsrc(in0 + (uint64_t)(more ? f + 1u : f) * fbytes);
-            const __amdgpu_buffer_rsrc_t rout = make_rsrc_ranged(out0 + (uint64_t)f * fbytes, (uint32_t)kSuperFrames * n);   // this group's 64 frames of the row
-            uint32_t stored = 0, pend_off = 0xFFFFFFFFu;         // RING: bytes of this item's output row already stored (a multiple of 1 KiB); the run read last row
-            uint4 pend = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-            for (int j = 0; j < kPk; ++j) asm volatile("" : "+v"(pk[j]));
-            {
-                uint2 e[2][8];
-                uint32_t wa[2], wb[2];
-                auto issue = [&](int u) {
-                    const int j = u >> 1, k = u & 1;
-                    wa[k] = (u & 1) ? d[j].z : d[j].x;
-                    wb[k] = (u & 1) ? d[j].w : d[j].y;
-                    const uint32_t frj = fr_of(j);
-                    const uint32_t bit = frj < 32u ? (uint32_t)__builtin_amdgcn_sbfe(am_lo, frj, 1) : (uint32_t)__builtin_amdgcn_sbfe(am_hi, frj - 32u, 1);
-                    const uint32_t lmj = bit & 0x80808080u;
-                    const uint32_t ta = (wa[k] & 0x7F7F7F7Fu) | lmj, tb = (wb[k] & 0x7F7F7F7Fu) | lmj;
-                    e[k][0] = lut_at(lds, ta, off, 0x0C0C0400u); e[k][1] = lut_at(lds, ta, off, 0x0C0C0500u);
-                    e[k][2] = lut_at(lds, ta, off, 0x0C0C0600u); e[k][3] = lut_at(lds, ta, off, 0x0C0C0700u);
-                    e[k][4] = lut_at(lds, tb, off, 0x0C0C0400u); e[k][5] = lut_at(lds, tb, off, 0x0C0C0500u);
-                    e[k][6] = lut_at(lds, tb, off, 0x0C0C0600u); e[k][7] = lut_at(lds, tb, off, 0x0C0C0700u);
-                };
-                auto recode4 = [&](uint32_t w, const uint2 &e0, const uint2 &e1, const uint2 &e2, const uint2 &e3) {
-                    const uint32_t p01 = __builtin_amdgcn_perm(e1.y, e0.y, 0x05040100u);
-                    const uint32_t p23 = __builtin_amdgcn_perm(e3.y, e2.y, 0x05040100u);
-                    const uint32_t sel = ((w >> 7) & 0x01010101u) | 0x06040200u;
-                    return __builtin_amdgcn_perm(p23, p01, sel);
-                };
-                uint32_t sum = 0, peak = 0, bsum = 0;
-                uint32_t o[4];
-                issue(0);
-#pragma unroll
-                for (int u = 0; u < 2 * QP; ++u) {
-                    const int j = u >> 1, k = u & 1;
-                    if (u + 1 < 2 * QP) issue(u + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    bsum = __builtin_amdgcn_sad_u8(wa[k], 0u, bsum);
-                    bsum = __builtin_amdgcn_sad_u8(wb[k], 0u, bsum);
-                    sum = sum + e[k][0].x + e[k][1].x; sum = sum + e[k][2].x + e[k][3].x;
-                    sum = sum + e[k][4].x + e[k][5].x; sum = sum + e[k][6].x + e[k][7].x;
-                    peak = max(max(peak, e[k][0].y), e[k][1].y); peak = max(max(peak, e[k][2].y), e[k][3].y);
-                    peak = max(max(peak, e[k][4].y), e[k][5].y); peak = max(max(peak, e[k][6].y), e[k][7].y);
-                    o[2 * k] = recode4(wa[k], e[k][0], e[k][1], e[k][2], e[k][3]);
-                    o[2 * k + 1] = recode4(wb[k], e[k][4], e[k][5], e[k][6], e[k][7]);
-                    if (k == 1) {
-                        uint2 ent = make_uint2(sum, (peak >> 16) | (bsum << 16) | probe_fail(d[j], 0xFFu << ps_of(j)));
-                        const uint32_t pj = po_of(j);
-                        // no branch on the per-lane tail flag: every lane issues both stores, the one that does not apply at an offset past
-                        // the frame row's buffer range (raw buffer stores out of range are dropped by the hardware)
-                        const bool tl = tail_of(j);
-                        if (tl) ent = make_uint2(d[j].z, d[j].w);               // the frame's last two dwords, raw, for the frame lane
-                        if (!RING) buf_st(rout, pj, 0u, make_uint4(o[0], o[1], o[2], o[3]));
-                        else {
-                            // this piece's bytes at their offset S of the output row (a payload piece: 16 bytes at its own offset; the
-                            // tail piece: the frame's last 4 T bytes, right behind piece Q - 1), parked in the ring dword by dword
-                            // (S is only dword aligned); then every whole KiB the row has reached goes out, 16 bytes per lane
-                            uint32_t S = tl ? pj + 16u - 4u * T : pj;
-                            asm volatile("" : "+v"(S));                  // derived per use: hoisted out of the frame loop the ring addresses of all rows cost 50 registers (and spilled)
-                            if (!tl) { ring[(S >> 2) & 511u] = o[0]; ring[((S >> 2) + 1u) & 511u] = o[1]; ring[((S >> 2) + 2u) & 511u] = o[2]; ring[((S >> 2) + 3u) & 511u] = o[3]; }
-                            else if (T == 2u) { ring[(S >> 2) & 511u] = o[2]; ring[((S >> 2) + 1u) & 511u] = o[3]; }
-                            else ring[(S >> 2) & 511u] = o[3];
-                            const uint32_t reach = (uint32_t)__builtin_amdgcn_readlane((int)(S + (tl ? 4u * T : 16u)), 63);   // end of the row's run
-                            // LDS operations of one wave execute in order, so the read below sees the dwords just parked and no wait is
-                            // needed between them — only the compiler must keep the order.  The run read in row j is stored in row j + 1
-                            // (pend): waiting for it at once would wait for every LUT read of the next unit issued before it.
-                            asm volatile("" ::: "memory");
-                            if (pend_off != 0xFFFFFFFFu) buf_st(rout, pend_off + 16u * lane, 0u, pend);
-                            pend_off = 0xFFFFFFFFu;
-                            if (reach - stored >= 1024u) {               // wave-uniform; a row adds at most 1 KiB, so at most one run is due
-                                pend = *reinterpret_cast<const uint4 *>(ring + (((stored >> 2) + 4u * lane) & 511u));
-                                pend_off = stored;
-                                stored += 1024u;
-                            }
-                            if (j == QP - 1) {                           // the item's last row: the pending run, then what is left (64 n % 1024 bytes, whole lines)
-                                if (pend_off != 0xFFFFFFFFu) buf_st(rout, pend_off + 16u * lane, 0u, pend);
-                                pend_off = 0xFFFFFFFFu;
-                                const uint32_t left = (uint32_t)kSuperFrames * n - stored;
-                                const uint4 v = *reinterpret_cast<const uint4 *>(ring + (((stored >> 2) + 4u * lane) & 511u));
-                                buf_st(rout, 16u * lane < left ? stored + 16u * lane : 0x80000000u, 0u, v);
-                            }
-                            asm volatile("" ::: "memory");
-                        }
-                        strip[j * 64 + lane] = ent;
-                        d[j] = buf_ld_pieces(rin, pj, 0u);
-                        sum = 0; peak = 0; bsum = 0;
-                    }
-                }
-            }
-            wave_lds_fence();
-            {
-                const uint2 *row = strip + lane * QP;
-                uint64_t sq = 0;
-                uint32_t peak = 0, bsum = 0, fail = 0, part = 0;
-#pragma unroll
-                for (int i = 0; i < Q; ++i) {
-                    const uint2 v = row[i];
-                    part += v.x;
-                    if ((i & 3) == 3 || i == Q - 1) { sq += part; part = 0; }
-                    peak = max(peak, v.y & 0x7FFFu);
-                    bsum += (v.y >> 16) & 0x7FFFu;
-                    fail |= v.y;
-                }
-                if (TAIL) {
-                    const uint2 tv = row[Q];
-                    const uint32_t lm = my_alaw ? 0x80808080u : 0u;
-                    const uint32_t tws[2] = {T == 2u ? tv.x : tv.y, tv.y};
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        if ((uint32_t)t < T) {
-                            const uint32_t w = tws[t], tt = (w & 0x7F7F7F7Fu) | lm;
-                            const uint2 e0 = lut_at(lds, tt, off, 0x0C0C0400u), e1 = lut_at(lds, tt, off, 0x0C0C0500u);
-                            const uint2 e2 = lut_at(lds, tt, off, 0x0C0C0600u), e3 = lut_at(lds, tt, off, 0x0C0C0700u);
-                            sq += (uint64_t)(e0.x + e1.x + e2.x + e3.x);
-                            peak = max(peak, max(max(e0.y, e1.y), max(e2.y, e3.y)) >> 16);
-                            bsum = __builtin_amdgcn_sad_u8(w, 0u, bsum);
-                        }
-                }
-                uint32_t bm, fl;
-                const uint4 rec = pack_stats(sq << 4, peak, bsum, n, my_alaw, (Q >= 4) && (fail >> 31) == 0u, bm, fl);
-                buf_st(make_rsrc(stats + ((uint64_t)f * C + c0)), lane * 16u, 0u, rec);
-                h_sumsq += sq << 4; h_lsum += bm;
+            frame_body(c0, f, rin, my_alaw, am_lo, am_hi, d, [&](uint64_t s16, uint32_t peak, uint32_t bm, uint32_t fl) {
+                h_sumsq += s16; h_lsum += bm;
                 h_pm = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16_t, h_pm), __builtin_bit_cast(v2u16_t, peak | (bm << 16))));
                 h_min = min(h_min, bm);
                 h_sc += ((fl & IGDSP_FLAG_SILENT) ? 1u : 0u) + ((fl & IGDSP_FLAG_CLIPPED) ? 0x10000u : 0u);
-            }
-            wave_lds_fence();
+            });
         }
         if (open) {
             igdsp_chan_hold h;
@@ -1199,6 +1421,18 @@ hipError_t launch_encode_table(const LaunchCfg &cfg, const int16_t *pcm, const u
     return hipGetLastError();
 }
 
+// Waves per block of the block-owned round-trip kernels.  Unlike the read-heavy kernels (the more waves the better: each has one
+// item of loads in flight) the 1 : 1 read / write mix is fastest with FEW resident waves per CU: at 160-byte frames 16 / 14 / 12 / 10
+// / 8 / 6 / 4 / 3 waves ran 0.4613 / 0.4607 / 0.4580 / 0.4552 / 0.4522 / 0.4498 / 0.4519 / 0.4785 ms in same-box A/B builds.
+static uint32_t rtb_waves(uint32_t n, int max_waves, uint32_t gpb)
+{
+    // about 60 KB of loads in flight per CU: 6 waves at 160 bytes per frame, 4 at 240, 10 (the strips' limit) at 80 and below; the tailed
+    // sizes want two more (164 bytes: 4 / 6 / 8 / 10 waves 0.6413 / 0.5146 / 0.4854 / 0.4915 ms; 240: 0.6636 / 0.6740 / 0.6746 / 0.6804)
+    uint32_t w = n >= 200u ? 4u : (n > 160u ? 8u : (n >= 120u ? 6u : 10u));
+    if (const char *e = std::getenv("IGDSP_RTB_WAVES")) w = (uint32_t)std::max(1, std::atoi(e));   // experiments
+    return std::max(std::max(gpb, 1u), std::min(w, (uint32_t)max_waves));                         // (a wave per owned group folds it at the block's end)
+}
+
 hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F,
                             uint32_t n, uint8_t *out, igdsp_frame_stats *stats, igdsp_chan_hold *hold,
                             const uint8_t *gate, int variant, hipStream_t s)
@@ -1226,6 +1460,25 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
         n_seg = std::max(1u, std::min(n_seg, std::max(1u, F / 8u)));
         n_seg = std::max(n_seg, F / 65535u + 1u);
         const uint32_t grid = blocks_for((uint64_t)n_groups_s * n_seg, kRtlWaves, (uint32_t)cfg.compute_units);
+        // block-owned form (same rule as for 160-byte frames below)
+        uint32_t gpb = 1u;
+        const uint32_t cus = (uint32_t)std::max(1, cfg.compute_units);
+        for (uint32_t g = 4u; g > 1u; g >>= 1) if (n_groups_s % g == 0u && n_groups_s / g >= cus) { gpb = g; break; }
+        if (const char *e = std::getenv("IGDSP_RT_GPB")) { const uint32_t g = (uint32_t)std::atoi(e); if ((g == 1u || g == 2u || g == 4u) && n_groups_s % g == 0u) gpb = g; }   // tests
+        const uint32_t blocks = n_groups_s / gpb, rounds = (blocks + cus - 1u) / cus;
+        bool blk = F <= 65535u && (uint64_t)blocks * 100u >= (uint64_t)rounds * cus * 85u;
+        if (const char *e = std::getenv("IGDSP_RT_BLK")) blk = F <= 65535u && std::atoi(e) != 0;       // experiments and tests
+        if (blk) {
+            const uint32_t gsh = gpb == 4u ? 2u : (gpb == 2u ? 1u : 0u);
+            const dim3 gb(blocks), bb(rtb_waves(n, kRtsbWaves, gpb) * 64u);
+#define IGDSP_RTSB(QV, TV)                                                                                                                                     \
+            if (Qn == QV && (Tn != 0u) == TV) {                                                                                                                 \
+                if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_G191, true>), gb, bb, 0, s, payload, codec, C, F, n, out, stats, hold, gate, gpb, n_groups_s, gsh);  \
+                else                           hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_SUN16, true>), gb, bb, 0, s, payload, codec, C, F, n, out, stats, hold, gate, gpb, n_groups_s, gsh); \
+            }
+            IGDSP_RTSB(1, true) IGDSP_RTSB(5, false) IGDSP_RTSB(10, true) IGDSP_RTSB(15, false)
+#undef IGDSP_RTSB
+        } else {
         const dim3 g3(grid), b3(kRtlWaves * 64);
 #define IGDSP_RTS(QV, TV)                                                                                                                                      \
         if (Qn == QV && (Tn != 0u) == TV) {                                                                                                                     \
@@ -1234,6 +1487,7 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
         }
         IGDSP_RTS(1, true) IGDSP_RTS(5, false) IGDSP_RTS(10, true) IGDSP_RTS(15, false)
 #undef IGDSP_RTS
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         const uint32_t c_first = n_groups_s * (uint32_t)kSuperFrames, c_count = C - c_first;
@@ -1254,7 +1508,20 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
         n_seg = std::max(1u, std::min(n_seg, std::max(1u, F / 8u)));
         n_seg = std::max(n_seg, F / 65535u + 1u);               // the fused kernels count silent / clipped frames of a segment in 16 bits
         const uint32_t grid = blocks_for((uint64_t)n_groups * n_seg, waves, (uint32_t)cfg.compute_units);
-        if (kernel_variant == 4) {
+        // block-owned form: gpb = as many groups per block (<= 4: the LDS) as still give every CU a block; taken when its blocks fill
+        // whole rounds of the CUs to 85 % and F fits the 16-bit silent / clipped counts
+        uint32_t gpb = 1u;
+        const uint32_t cus = (uint32_t)std::max(1, cfg.compute_units);
+        for (uint32_t g = 4u; g > 1u; g >>= 1) if (n_groups % g == 0u && n_groups / g >= cus) { gpb = g; break; }
+        if (const char *e = std::getenv("IGDSP_RT_GPB")) { const uint32_t g = (uint32_t)std::atoi(e); if ((g == 1u || g == 2u || g == 4u) && n_groups % g == 0u) gpb = g; }   // tests
+        const uint32_t blocks = n_groups / gpb, rounds = (blocks + cus - 1u) / cus;
+        bool blk = kernel_variant != 4 && F <= 65535u && (uint64_t)blocks * 100u >= (uint64_t)rounds * cus * 85u;
+        if (const char *e = std::getenv("IGDSP_RT_BLK")) blk = kernel_variant != 4 && F <= 65535u && std::atoi(e) != 0;   // experiments and tests
+        if (blk) {
+            const uint32_t gsh = gpb == 4u ? 2u : (gpb == 2u ? 1u : 0u);
+            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_blk64<IGDSP_ENC_G191>), dim3(blocks), dim3(rtb_waves(n, kRtbWaves, gpb) * 64u), 0, s, payload, codec, C, F, out, stats, hold, gate, gpb, gsh);
+            else                           hipLaunchKernelGGL((k_roundtrip_blk64<IGDSP_ENC_SUN16>), dim3(blocks), dim3(rtb_waves(n, kRtbWaves, gpb) * 64u), 0, s, payload, codec, C, F, out, stats, hold, gate, gpb, gsh);
+        } else if (kernel_variant == 4) {
             if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_G191>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);
             else                           hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_SUN16>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);
         } else {

@@ -765,7 +765,7 @@ hipError_t launch_decode_meter_rtp(const LaunchCfg &cfg, const uint8_t *slots, c
         const uint32_t grid = blocks_for((uint64_t)win->n_groups * win->n_seg, waves, (uint32_t)cfg.compute_units);
         uint32_t *noq = nullptr;                           // units are assigned statically (a grid apart), no device queue
         if (win->gpb != 0u) {                              // block-owned channel groups: one block per gpb groups
-            blk = dim3(kRtpWaves * 64);
+            if (waves < win->gpb) blk = dim3(win->gpb * 64);      // (a wave per group folds it at the block's end)
             const uint32_t gridb = win->n_groups / win->gpb;
             if (stride == 0)          hipLaunchKernelGGL((k_meter_rtp64<true, true, false, 2>), dim3(gridb), blk, 0, s, slots, sizes, codec, C, n_frames, 192u, 20u, stats, info, agg, rank, noq, radio, *win);
             else if (radio != nullptr) hipLaunchKernelGGL((k_meter_rtp64<true, false, true, 2>), dim3(gridb), blk, 0, s, slots, sizes, codec, C, n_frames, stride, 12u, stats, info, agg, rank, noq, radio, *win);
