@@ -396,12 +396,16 @@ def test_roundtrip_peakhold_vs_oracle(ctx, orc, variant, F_):
 @pytest.mark.parametrize("C_,F_,n", [(4, 50, 160), (33, 5, 160), (64, 9, 160), (100, 7, 160), (200, 3, 164), (7, 4, 24), (65, 2, 255),
                                      (130, 70, 160), (1, 1, 1), (3, 2, 159), (700, 2, 160), (130, 70, 164), (128, 9, 240), (64, 12, 24),
                                      (192, 33, 80), (65, 10, 168), (256, 5, 20), (128, 4, 172), (128, 4, 96)])
-def test_roundtrip_every_shape_vs_oracle(ctx, orc, kernel, C_, F_, n):
+@pytest.mark.parametrize("blk", ["0", "1"])
+def test_roundtrip_every_shape_vs_oracle(ctx, orc, monkeypatch, kernel, C_, F_, n, blk):
     """igdsp_roundtrip_peakhold serves every geometry: whole groups of 64 channels of 160-byte frames through the fused
-    kernel, the C % 64 left-over channels and every other n (164, 24, ... roip_ed137.cpp:6561-6562) / BASELINE config #1's
+    kernels, the C % 64 left-over channels and every other n (164, 24, ... roip_ed137.cpp:6561-6562) / BASELINE config #1's
     4 channels through the general wave-per-channel kernel; codes, records and hold equal the oracle's, with gates and
-    pre-existing hold state."""
+    pre-existing hold state.  blk: the fused kernels' two work distributions — 0 = a wave walks a segment of one group's frames
+    (windows in registers), 1 = a block owns groups and hands out single frames (windows in LDS); the launcher's own rule only
+    takes the second where its blocks fill the chip."""
     torch = gu.torch_cuda()
+    monkeypatch.setenv("IGDSP_RT_BLK", blk)
     rng = np.random.default_rng(C_ * 1000 + F_ * 10 + n)
     codec = rng.choice(np.array([0, 8], np.uint8), size=C_)
     payload = orc.gen_uniform(F_ * C_ * n, seed=C_ + n).reshape(F_, C_, n).copy()
@@ -428,6 +432,34 @@ def test_roundtrip_every_shape_vs_oracle(ctx, orc, kernel, C_, F_, n):
         ghold = gu.to_host(d_hold, capi.CHAN_HOLD)
         for f in capi.CHAN_HOLD.names:
             assert np.array_equal(ghold[f], ehold[f]), (f, variant)
+
+
+@pytest.mark.parametrize("gpb,C_,F_,n", [("4", 512, 37, 160), ("2", 384, 50, 160), ("4", 256, 21, 164), ("2", 128, 40, 240), ("4", 256, 30, 80),
+                                          ("4", 256, 64, 24), ("1", 192, 3, 160), ("4", 256, 1, 160)])
+def test_roundtrip_block_form_groups_per_block(ctx, orc, monkeypatch, gpb, C_, F_, n):
+    """The block-owned round trip at 4 / 2 / 1 channel groups per block (odd blocks start in the middle of the frames; F = 1 and
+    odd F included), every fused frame size, against the oracle and byte for byte against the static form."""
+    torch = gu.torch_cuda()
+    rng = np.random.default_rng(C_ + F_ + n)
+    codec = rng.choice(np.array([0, 8], np.uint8), size=C_)
+    payload = orc.gen_uniform(F_ * C_ * n, seed=C_ + F_).reshape(F_, C_, n).copy()
+    payload[F_ // 2, ::5, :] = 0xD5
+    gate = (rng.integers(0, 5, C_) != 0).astype(np.uint8)
+    hold0 = gu.new_hold(C_)
+    hold0["peak_hold"][::7] = 20000
+    hold0["count"][::3] = 11
+    outs = []
+    for blk in ("1", "0"):
+        monkeypatch.setenv("IGDSP_RT_BLK", blk)
+        monkeypatch.setenv("IGDSP_RT_GPB", gpb)
+        d_out, d_st, d_hold = gu.dev_zeros(F_ * C_ * n, 0xEE), gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.to_dev(hold0)
+        ctx.roundtrip_peakhold(gu.to_dev(payload), gu.to_dev(codec), C_, F_, n, d_out, d_st, d_hold, gate=gu.to_dev(gate), variant=capi.ENC_G191)
+        torch.cuda.synchronize()
+        outs.append((gu.to_host(d_out, np.uint8).tobytes(), gu.to_host(d_st, np.uint8).tobytes(), gu.to_host(d_hold, np.uint8).tobytes()))
+    assert outs[0] == outs[1]
+    eout, est, ehold = orc.roundtrip_peakhold(payload, codec, hold0.copy().view(orc.CHAN_HOLD), gate=gate, variant=capi.ENC_G191)
+    assert outs[0][0] == eout.tobytes()
+    assert np.frombuffer(outs[0][2], capi.CHAN_HOLD).tobytes() == np.ascontiguousarray(ehold).tobytes()
 
 
 @pytest.mark.parametrize("variant", [capi.ENC_SUN16, capi.ENC_G191])
