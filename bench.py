@@ -132,6 +132,23 @@ def _cpu_model() -> str:
     return "unknown"
 
 
+def _block_form(channels, env):
+    """The launchers' rule for the block-owned form of the round trip / the fused window (igdsp_k_codec.hip launch_roundtrip,
+    igdsp_capi.hip igdsp_decode_meter_window): as many channel groups per block (<= 4) as still give every CU a block, taken when
+    the blocks fill whole rounds of the CUs to 85 %.  Only used to NAME the dominant kernel in the JSON line."""
+    import torch
+    e = os.environ.get(env)
+    if e is not None:
+        return int(e) != 0
+    n_groups, cus = channels // 64, max(1, torch.cuda.get_device_properties(0).multi_processor_count)
+    if n_groups == 0:
+        return False
+    gpb = next((g for g in (4, 2) if n_groups % g == 0 and n_groups // g >= cus), 1)
+    blocks = n_groups // gpb
+    rounds = (blocks + cus - 1) // cus
+    return blocks * 100 >= rounds * cus * 85
+
+
 def main():
     args = parse()
     import numpy as np
@@ -448,7 +465,7 @@ def main():
     value = total_samples / dt / 1e6
     bps = BYTES_PER_SAMPLE[args.mode] if n == N_SAMPLES else (n + 1 + 16 + {"store": 2 * n, "roundtrip": n}.get(args.mode, 0)) / n
     achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9
-    kernel_name = "k_encode_lut16" if args.mode == "encode" else "k_wav_expand16" if args.mode == "wav" else "k_meter_rtp64" if args.mode in ("rtp", "packets", "window") else "k_depayload64" if args.mode == "depayload" else ("k_roundtrip_chunk64" if args.variant == 4 else "k_roundtrip_lut64" if n == N_SAMPLES else "k_roundtrip_strided") if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64" if n == N_SAMPLES else "k_meter_tiny" if (16 <= n <= 32 and args.mode == "meter") else "k_meter_strided" if ((n >> 4) in (1, 4, 5, 6, 8, 10, 12, 15) and (n >> 2) & 3 != 3 and n not in (244, 248)) else "k_meter_image")
+    kernel_name = "k_encode_lut16" if args.mode == "encode" else "k_wav_expand16" if args.mode == "wav" else "k_meter_rtp64" if args.mode in ("rtp", "packets", "window") else "k_depayload64" if args.mode == "depayload" else ("k_roundtrip_chunk64" if args.variant == 4 else ("k_roundtrip_blk64" if _block_form(C_, "IGDSP_RT_BLK") else "k_roundtrip_lut64") if n == N_SAMPLES else "k_roundtrip_strided") if args.mode == "roundtrip" else ("k_meter_wave_per_frame" if args.variant == 1 else "k_meter_chunk64" if n == N_SAMPLES else "k_meter_tiny" if (16 <= n <= 32 and args.mode == "meter") else "k_meter_strided" if ((n >> 4) in (1, 4, 5, 6, 8, 10, 12, 15) and (n >> 2) & 3 != 3 and n not in (244, 248)) else "k_meter_image")
 
     def frac_of(ms):
         return None if ms is None else round(samples_per_step_rank * bps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

@@ -20,7 +20,7 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 STEPS = 20                    # tools/profile.sh runs bench.py --steps 20: the LAST 20 dispatches of the kernel are the timed region
 C_, F_ = 65536, 128
-KERNEL = {"meter": "k_meter_chunk64", "store": "k_meter_chunk64", "roundtrip": "k_roundtrip_lut64", "depayload": "k_depayload64",
+KERNEL = {"meter": "k_meter_chunk64", "store": "k_meter_chunk64", "roundtrip": "k_roundtrip_blk64", "depayload": "k_depayload64",
           "rtp": "k_meter_rtp64", "packets": "k_meter_rtp64", "window": "k_meter_rtp64", "encode": "k_encode_lut16", "wav": "k_wav_expand16", "meter164": "k_meter_strided",
           "store164": "k_meter_strided", "roundtrip164": "k_roundtrip_strided", "meter24": "k_meter_tiny"}
 BPS = {"meter": (160 + 1 + 16) / 160, "store": (160 + 1 + 16 + 320) / 160, "roundtrip": (160 + 1 + 16 + 160) / 160,
