@@ -185,12 +185,16 @@ __global__ __launch_bounds__(1024) void k_encode_v8_table(const int16_t *__restr
 // PCM word, so a sample costs ~2 VALU + one ds_read_u8 and the kernel sits on the copy-like HBM bound.  Frame /
 // channel bookkeeping is incremental (adds and compares): the grid-stride step is decomposed once per thread into
 // whole frames + groups, so no division runs inside the loop.
+#ifndef IGDSP_ENC_WAVES
+#define IGDSP_ENC_WAVES 16
+#endif
+constexpr int kEncWaves = IGDSP_ENC_WAVES;
 template <int VARIANT>
-__global__ __launch_bounds__(1024) void k_encode_lut16(const int16_t *__restrict__ pcm, const uint8_t *__restrict__ codec,
+__global__ __launch_bounds__(kEncWaves * 64) void k_encode_lut16(const int16_t *__restrict__ pcm, const uint8_t *__restrict__ codec,
                                                        uint32_t C, uint32_t n, uint32_t n_groups, uint8_t *__restrict__ out,
                                                        uint32_t *gqueue)
 {
-    constexpr int kW = 16;                                         // launched with 1024 threads
+    constexpr int kW = kEncWaves;
     __shared__ uint8_t tab[2 * 65536];
     __shared__ BlockQueue<kW> bq;
     uint32_t gb1 = 0;
@@ -1390,8 +1394,8 @@ hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t
     if (v8 && n_samples >= (1u << 25) && (n_samples >> 3) < 0xFFFF0000ull) {   // large batches: full 16-bit table, one block per CU (32-bit group ids)
         const uint32_t groups = (uint32_t)(n_samples >> 3);    // 32-bit group ids (checked above)
         const uint32_t grid = blocks_for(groups, 1024, (uint32_t)cfg.compute_units);
-        if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_G191>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, groups, out, cfg.gqueue);
-        else                           hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_SUN16>), dim3(grid), dim3(1024), 0, s, pcm, codec, C, n, groups, out, cfg.gqueue);
+        if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_G191>), dim3(grid), dim3(kEncWaves * 64), 0, s, pcm, codec, C, n, groups, out, cfg.gqueue);
+        else                           hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_SUN16>), dim3(grid), dim3(kEncWaves * 64), 0, s, pcm, codec, C, n, groups, out, cfg.gqueue);
     } else if (v8 && n_samples >= (1u << 22)) {                 // big batches: table-driven compressor, persistent blocks
         const uint64_t groups = n_samples >> 3;
         const uint32_t grid = blocks_for(groups, 1024, (uint32_t)cfg.compute_units * 2u);

@@ -207,9 +207,15 @@ __device__ __forceinline__ void process_half(const uint2 *lut, uint2 *strip_half
 // Balance: block b owns super-chunks b, b+G, b+2G, ...; its 16 waves pull the next one from an LDS
 // counter, so the waves of a CU finish within one iteration of each other.
 // ============================================================================
-// waves per block: 16 (1024 threads, 128 VGPRs) for the meter-only kernel; the PCM-store variants carry
-// eight more live registers per lane and run 12 waves (768 threads, up to 168 VGPRs) instead of spilling.
-template <bool STORE_PCM> struct ChunkGeom { static constexpr int kWaves = STORE_PCM ? 12 : kWavesPerBlock; };
+// waves per block: 16 (1024 threads, 128 VGPRs) for the meter-only kernel: a read-heavy kernel wants every wave it can get, each
+// has one super-chunk of loads in flight.  The PCM-store variant writes two bytes for every byte it reads, and a 1 : 2 mix is
+// fastest with FEW resident waves per CU — 12 / 10 / 8 / 6 / 5 / 4 / 3 / 2 waves: 0.6706 / 0.6680 / 0.6636 / 0.6573 / 0.6520 / 0.6388 / 0.6995 /
+// 1.013 ms in same-box A/B builds (late round 3; 12 had been chosen for its registers) — every wave is one more front of 20 KiB
+// write bursts, and four already keep enough loads in flight.
+#ifndef IGDSP_STORE_WAVES
+#define IGDSP_STORE_WAVES 4
+#endif
+template <bool STORE_PCM> struct ChunkGeom { static constexpr int kWaves = STORE_PCM ? IGDSP_STORE_WAVES : kWavesPerBlock; };
 
 // DIAG: a separate diagnostic instantiation (never the shipped path) that stamps where a
 // wave's cycles go; the stamps leave only through `diag`, no output is computed from them.
@@ -670,7 +676,12 @@ __global__ __launch_bounds__(kImgMaxWaves * 64) void k_meter_image(
 // ============================================================================
 // STORE: the decoded int16 PCM goes out as well (pcm[F][C][n], dword aligned): every payload piece stores its 32 bytes as two
 // dword-aligned 16-byte stores, the tail piece the 8 T bytes of the frame's tail samples; 12 waves (eight more live registers).
-template <int QP, bool STORE = false> struct StridedGeom { static constexpr int kWaves = STORE ? (QP <= 2 ? 16 : (QP <= 11 ? 12 : 10)) : (QP <= 11 ? 16 : 12); };
+#ifndef IGDSP_SSTORE_WAVES
+#define IGDSP_SSTORE_WAVES 0
+#endif
+// (the PCM-store variant, a 1 : 2 read : write mix, is fastest with few waves, as k_meter_chunk64<STORE>: 164-byte frames 12 / 8 / 6 / 5 / 4
+// waves 0.7264 / 0.7133 / 0.7036 / 0.741 / 0.861 ms; 240: 10 / 8 / 6 / 5 / 4 0.9926 / 0.9865 / 0.980 / 0.9766 / 0.9975; 80: 12 / 10 / 8 / 6 0.3472 / 0.3462 / 0.3424 / 0.3402)
+template <int QP, bool STORE = false> struct StridedGeom { static constexpr int kWaves = STORE ? (IGDSP_SSTORE_WAVES ? IGDSP_SSTORE_WAVES : (QP <= 2 ? 16 : 6)) : (QP <= 11 ? 16 : 12); };
 
 template <int Q, bool TAIL, bool AGG, bool STORE = false>
 __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 64)) void k_meter_strided(
