@@ -181,12 +181,15 @@ __global__ __launch_bounds__(1024) void k_encode_v8_table(const int16_t *__restr
 }
 
 // Large batches: the compressor as a FULL 16-bit table, tab[law][uint16(v)] = 128 KiB of LDS built per block by
-// enc_uni (one block per CU, 16 waves).  The whole LDS address {law, v.hi, v.lo} is one v_perm_b32 of the loaded
+// enc_uni (one block per CU, kEncWaves waves).  The whole LDS address {law, v.hi, v.lo} is one v_perm_b32 of the loaded
 // PCM word, so a sample costs ~2 VALU + one ds_read_u8 and the kernel sits on the copy-like HBM bound.  Frame /
 // channel bookkeeping is incremental (adds and compares): the grid-stride step is decomposed once per thread into
 // whole frames + groups, so no division runs inside the loop.
+// Waves per block (late round 3, same-box A/B builds): 16 / 14 / 12 / 10 / 8 / 6 / 4 → 0.651–0.662 / 0.650–0.658 / 0.641–0.642 / 0.636–0.637 / 0.646–0.648 /
+// 0.770 / 1.05 ms.  The 2 : 1 read : write mix sits between the read-heavy kernels (the more waves the better) and the store / round-trip
+// kernels (4–6): ten waves of 8 KiB chunks keep enough loads in flight, more only add write fronts.
 #ifndef IGDSP_ENC_WAVES
-#define IGDSP_ENC_WAVES 16
+#define IGDSP_ENC_WAVES 10
 #endif
 constexpr int kEncWaves = IGDSP_ENC_WAVES;
 template <int VARIANT>
