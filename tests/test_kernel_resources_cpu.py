@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-HOT = ("k_meter_chunk64", "k_meter_rtp64", "k_meter_image", "k_meter_strided", "k_meter_tiny", "k_meter_wave_per_frame", "k_roundtrip_lut64", "k_roundtrip_chunk64",
+HOT = ("k_meter_chunk64", "k_meter_rtp64", "k_meter_image", "k_meter_strided", "k_meter_tiny", "k_meter_wave_per_frame", "k_roundtrip_lut64", "k_roundtrip_blk64", "k_roundtrip_strided", "k_roundtrip_chunk64",
        "k_roundtrip_general", "k_encode_lut16", "k_encode_v8", "k_depayload64", "k_wav_expand16", "k_flush_fold", "k_window_update", "k_window_finish")
 
 
@@ -42,7 +42,9 @@ def test_launch_geometry_budgets(resources):
     by = {r["demangled"]: r for r in resources}
     lim = {"k_meter_chunk64<false, true, false>": 128, "k_meter_chunk64<false, false, false>": 128,      # 16 waves / CU
            "k_meter_chunk64<true, true, false>": 168, "k_meter_chunk64<true, false, false>": 168,        # 12 waves / CU
-           "k_roundtrip_lut64<0>": 168, "k_roundtrip_lut64<1>": 168, "k_encode_lut16<0>": 128, "k_encode_lut16<1>": 128}
+           "k_roundtrip_lut64<0>": 168, "k_roundtrip_lut64<1>": 168, "k_encode_lut16<0>": 128, "k_encode_lut16<1>": 128,
+           "k_roundtrip_blk64<0>": 168, "k_roundtrip_blk64<1>": 168,                                      # up to 12 waves / CU (6 launched)
+           "k_meter_rtp64<true, false, false, 2>": 170, "k_meter_rtp64<true, false, true, 2>": 170, "k_meter_rtp64<true, true, false, 2>": 170}   # 12 waves / CU
     for k, v in lim.items():
         r = by["void igdsp::" + k]
         assert r["vgpr"] <= v, (k, r)
