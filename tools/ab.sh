@@ -1,7 +1,8 @@
 #!/bin/bash
 # A/B: rebuild with -D flags on the box and bench each; usage: tools/ab.sh "<flags A>" "<flags B>" ...  (bench args via BENCH_ARGS).
 # The knobs are the #ifdef / #ifndef switches the kernel sources carry themselves: -DIGDSP_NT_STORE=1, -DIGDSP_NO_SPREAD,
-# -DIGDSP_SPREAD_METER=1, -DIGDSP_RT_WAVES=N, -DIGDSP_RTL_WAVES=N, and, for the fused window kernel, -DIGDSP_WIN_NOBOOK /
+# -DIGDSP_SPREAD_METER=1, -DIGDSP_RT_WAVES=N, -DIGDSP_RTL_WAVES=N, the waves per CU of the write-heavy kernels (-DIGDSP_STORE_WAVES=N,
+# -DIGDSP_SSTORE_WAVES=N, -DIGDSP_ENC_WAVES=N), -DIGDSP_TINY_LATE, -DIGDSP_BLK_NORUN / -DIGDSP_BLK_STAMP (tools/blk_stamp.py) and, for the fused window kernel, -DIGDSP_WIN_NOBOOK /
 # -DIGDSP_WIN_ASC (those two produce WRONG windows on purpose: what the kernel's time does not depend on).  (Round 1's
 # wrong-result IGDSP_AB_* knobs lived in a patch against a file that no longer exists; they are in git history.)
 for fl in "$@"; do
