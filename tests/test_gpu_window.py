@@ -288,6 +288,12 @@ def test_fused_window_without_records(ctx, orc, monkeypatch, blk):
     assert outs[0] == outs[1]
     _, _, _, _, eh, ep = _expected(orc, pk, sizes, radio, codec, capi.GATE_PTT, 4, None, hold0, probe0)
     assert outs[1] == (eh.tobytes(), ep.tobytes())
+    # a window without run tracking (d_probe == NULL): the same hold
+    d_hold = gu.to_dev(hold0)
+    win = ctx.window(d_hold, gate_mode=capi.GATE_PTT, work=gu.dev_zeros(ctx.window_work_bytes(C_)))
+    ctx.decode_meter_window(capi.PKT_PACKED, gu.to_dev(pk), gu.to_dev(sizes), gu.to_dev(codec), None, C_, F_, stride, 20, None, win)
+    torch.cuda.synchronize()
+    assert gu.to_host(d_hold, capi.CHAN_HOLD).tobytes() == eh.tobytes()
     # off the fused path the records are needed
     import ctypes as C
     w = ctx.window(gu.to_dev(hold0))
