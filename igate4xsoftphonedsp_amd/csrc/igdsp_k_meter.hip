@@ -977,10 +977,15 @@ __global__ __launch_bounds__((StridedGeom<Q + (TAIL ? 1 : 0), STORE>::kWaves * 6
 // ds_read_b32 per sample, the law is one bit of the lane's table offset), keeps sum / max / byte-sum in three registers — 32
 // samples x 2^26 still fit 32 bits — and stores its 16-byte record: 64 lanes = one 1 KiB store, no LDS hand-off at all.  No frame
 // is long enough for the silence probe (bytes 28 / 38 / 48 need n > 48).  Items of 64 frames; a queue slot stands for kTinySlot
-// consecutive items; kTinyDepth items of loads stay in flight per wave across slot boundaries.
+// consecutive items (four: the slots are what the block / device queue balances); kTinyDepth items of loads stay in flight per wave across slot boundaries.
 // ============================================================================
 constexpr int kTinyWaves = 16, kTinyDepth = 4;
-constexpr uint32_t kTinySlot = 16;
+// items per queue slot (>= kTinyDepth: the prologue).  16 made a wave's share two slots, i.e. static in effect; 32 / 16 / 8 / 4 items: 0.0683 /
+// 0.0693 / 0.0682 / 0.0676 ms at 24-byte frames, 65 536 x 128 (same-box A/B builds, late round 3)
+#ifndef IGDSP_TINY_SLOT
+#define IGDSP_TINY_SLOT 4
+#endif
+constexpr uint32_t kTinySlot = IGDSP_TINY_SLOT;
 
 template <int N4, bool AGG>
 __global__ __launch_bounds__(kTinyWaves * 64) void k_meter_tiny(
