@@ -190,14 +190,13 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
     const uint64_t t_stamp0 = wall_clock64();
 #endif
     if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);
+    igdsp_chan_probe p0 = igdsp_chan_probe{0u, 0u};              // WIN == 2: the channels' runs so far (the load's latency hides under the table fill)
+    if (WIN == 2 && threadIdx.x < win.gpb * 64u && win.probe != nullptr) p0 = win.probe[blockIdx.x * win.gpb * 64u + threadIdx.x];
     fill_lut(lds);
     if (threadIdx.x == 0) { bq_init(bq, gqueue, gridDim.x, gb1); agg_block_init(aggb); if (WIN == 2) { bq.next = 0u; w_ticket = 0u; } }
     if (WIN == 2) {
         for (uint32_t i = threadIdx.x; i < 7u * (uint32_t)kWinBlkCh; i += blockDim.x) wst[i] = i >= 6u * (uint32_t)kWinBlkCh ? 255u : 0u;
-        if (threadIdx.x < win.gpb * 64u && win.probe != nullptr) {
-            const igdsp_chan_probe p0 = win.probe[blockIdx.x * win.gpb * 64u + threadIdx.x];
-            w_run[threadIdx.x] = p0.run; w_alarms[threadIdx.x] = p0.alarms;
-        }
+        if (threadIdx.x < win.gpb * 64u) { w_run[threadIdx.x] = p0.run; w_alarms[threadIdx.x] = p0.alarms; }
         if (threadIdx.x < 4u) w_commit[threadIdx.x] = 0u;
         if (threadIdx.x < 4u * (uint32_t)kWinRing) w_flag[threadIdx.x] = 0u;
     }
