@@ -720,7 +720,7 @@ template <int VARIANT>
 __global__ __launch_bounds__(kRtbWaves * 64) void k_roundtrip_blk64(
     const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F,
     uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats, igdsp_chan_hold *__restrict__ hold,
-    const uint8_t *__restrict__ gate, uint32_t gpb, uint32_t gsh)
+    const uint8_t *__restrict__ gate, uint32_t gpb, uint32_t gsh, uint32_t mid_start)
 {
     __shared__ uint2 lds[kLutEntries + kRtbWaves * kStripEntries];
     // {sum of squares (2 dwords), byte-mean sum, peak-hold, level max, level min, silent | clipped << 16} x kRtBlkCh channels
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(kRtbWaves * 64) void k_roundtrip_blk64(
     pack_piece_consts(lane, fr5, pm5);
     const uint64_t fbytes = (uint64_t)C * kFrame;                  // bytes between two frames of one channel group
     const uint32_t b_first = blockIdx.x * gpb, b_items = F * gpb;
-    const uint32_t f_shift = (blockIdx.x & 1u) ? F / 2u : 0u;      // odd blocks start in the middle of the launch
+    const uint32_t f_shift = (mid_start != 0u && (blockIdx.x & 1u)) ? F / 2u : 0u;      // odd blocks start in the middle of the launch (spread outputs)
     auto grab = [&]() -> uint32_t {                                // block-local item number, 0xFFFFFFFF = none left
         uint32_t v = 0;
         if (lane == 0) v = atomicAdd(&q_next, 1u);
@@ -1022,8 +1022,8 @@ __global__ __launch_bounds__((BLK ? kRtsbWaves : kRtlWaves) * 64) void k_roundtr
         wave_lds_fence();
     };
     if (BLK) {
-        const uint32_t gpb = n_seg, gsh = order, b_first = blockIdx.x * gpb, b_items = F * gpb;
-        const uint32_t f_shift = (blockIdx.x & 1u) ? F / 2u : 0u;
+        const uint32_t gpb = n_seg, gsh = order & 3u, b_first = blockIdx.x * gpb, b_items = F * gpb;
+        const uint32_t f_shift = ((order & 4u) != 0u && (blockIdx.x & 1u)) ? F / 2u : 0u;      // (order bit 2: the output is spread over two classes)
         auto grab = [&]() -> uint32_t {
             uint32_t v = 0;
             if (lane == 0) v = atomicAdd(&q_next, 1u);
@@ -1450,6 +1450,8 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
     // alternating in one process.  IGDSP_RT_ORDER overrides (experiments, and the test of the order the placement would pick).
     uint32_t order = cfg.out_spread ? 1u : 0u;
     if (const char *e = std::getenv("IGDSP_RT_ORDER")) order = (uint32_t)std::atoi(e);
+    uint32_t mid_start = cfg.out_spread ? 1u : 0u;               // block-owned form: odd blocks walk the frames from the middle (both halves of a spread output written at any moment)
+    if (const char *e = std::getenv("IGDSP_RT_MID")) mid_start = std::atoi(e) != 0 ? 1u : 0u;   // experiments
     // The fused channel-group-major kernels take whole groups of 64 channels of 160-byte frames in 16-byte aligned
     // buffers; the C % 64 channels left over, and every other shape (n != 160, unaligned buffers), go through
     // k_roundtrip_general on the same stream.  kernel_variant 4 selects the compressor-cell-table form of the fused
@@ -1480,8 +1482,8 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
             const dim3 gb(blocks), bb(rtb_waves(n, kRtsbWaves, gpb) * 64u);
 #define IGDSP_RTSB(QV, TV)                                                                                                                                     \
             if (Qn == QV && (Tn != 0u) == TV) {                                                                                                                 \
-                if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_G191, true>), gb, bb, 0, s, payload, codec, C, F, n, out, stats, hold, gate, gpb, n_groups_s, gsh);  \
-                else                           hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_SUN16, true>), gb, bb, 0, s, payload, codec, C, F, n, out, stats, hold, gate, gpb, n_groups_s, gsh); \
+                if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_G191, true>), gb, bb, 0, s, payload, codec, C, F, n, out, stats, hold, gate, gpb, n_groups_s, gsh | (mid_start << 2));  \
+                else                           hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_SUN16, true>), gb, bb, 0, s, payload, codec, C, F, n, out, stats, hold, gate, gpb, n_groups_s, gsh | (mid_start << 2)); \
             }
             IGDSP_RTSB(1, true) IGDSP_RTSB(5, false) IGDSP_RTSB(10, true) IGDSP_RTSB(15, false)
 #undef IGDSP_RTSB
@@ -1526,8 +1528,8 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
         if (const char *e = std::getenv("IGDSP_RT_BLK")) blk = kernel_variant != 4 && F <= 65535u && std::atoi(e) != 0;   // experiments and tests
         if (blk) {
             const uint32_t gsh = gpb == 4u ? 2u : (gpb == 2u ? 1u : 0u);
-            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_blk64<IGDSP_ENC_G191>), dim3(blocks), dim3(rtb_waves(n, kRtbWaves, gpb) * 64u), 0, s, payload, codec, C, F, out, stats, hold, gate, gpb, gsh);
-            else                           hipLaunchKernelGGL((k_roundtrip_blk64<IGDSP_ENC_SUN16>), dim3(blocks), dim3(rtb_waves(n, kRtbWaves, gpb) * 64u), 0, s, payload, codec, C, F, out, stats, hold, gate, gpb, gsh);
+            if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_blk64<IGDSP_ENC_G191>), dim3(blocks), dim3(rtb_waves(n, kRtbWaves, gpb) * 64u), 0, s, payload, codec, C, F, out, stats, hold, gate, gpb, gsh, mid_start);
+            else                           hipLaunchKernelGGL((k_roundtrip_blk64<IGDSP_ENC_SUN16>), dim3(blocks), dim3(rtb_waves(n, kRtbWaves, gpb) * 64u), 0, s, payload, codec, C, F, out, stats, hold, gate, gpb, gsh, mid_start);
         } else if (kernel_variant == 4) {
             if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_G191>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);
             else                           hipLaunchKernelGGL((k_roundtrip_chunk64<IGDSP_ENC_SUN16>), dim3(grid), dim3(kRtWaves * 64), 0, s, payload, codec, C, F, out, stats, hold, gate, n_seg, n_groups);
