@@ -365,3 +365,46 @@ def test_fused_window_full_size_equals_two_step_on_device(ctx, orc, monkeypatch,
     assert gu.to_host(outs[0][2], capi.CHAN_HOLD)[pick].tobytes() == eh.tobytes()
     assert gu.to_host(outs[0][3], capi.CHAN_PROBE)[pick].tobytes() == ep.tobytes()
     assert ep["alarms"].sum() > probe0[pick]["alarms"].sum() and ((st["flags"] & capi.FLAG_PROBE_D5) != 0).mean() > 0.5
+
+
+def test_block_forms_over_two_rounds_of_blocks(ctx, orc, monkeypatch):
+    """131 072 channels = 512 blocks of four groups: two rounds of blocks on the 256 CUs (the launchers' rule still picks the
+    block-owned forms).  Fused window against the two-step route on the device; block-owned round trip against the static form."""
+    torch = gu.torch_cuda()
+    C_, F_, stride = 131072, 12, 180
+    rng = np.random.default_rng(21)
+    d_pk = torch.empty((F_ * C_ * stride,), dtype=torch.uint8, device="cuda")
+    ctx.gen_uniform(d_pk, d_pk.numel(), seed=5, stream=torch.cuda.current_stream().cuda_stream)
+    v = d_pk.view(F_, C_, stride)
+    v[:, :, 0] = 0x90; v[:, :, 1] = 8
+    v[:, :, 12] = 0x01; v[:, :, 13] = 0x67; v[:, :, 14] = 0x00; v[:, :, 15] = 0x01
+    v[:, :, 20:][torch.from_numpy(rng.random((F_, C_)) < 0.6).cuda()] = 0xD5
+    codec = torch.full((C_,), 8, dtype=torch.uint8, device="cuda")
+    hold0, probe0 = _start_state(rng, C_)
+    outs = []
+    for fused in (True, False):
+        d_hold, d_probe = gu.to_dev(hold0), gu.to_dev(probe0)
+        d_st, d_info = gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.dev_zeros(F_ * C_ * 8, 0xEE)
+        win = ctx.window(d_hold, gate_mode=capi.GATE_SQU_OR_PTT, probe=d_probe, work=gu.dev_zeros(ctx.window_work_bytes(C_)), probe_alarm=3)
+        if fused:
+            ctx.decode_meter_window(capi.PKT_PACKED, d_pk, None, codec, None, C_, F_, stride, 20, d_st, win, info=d_info)
+        else:
+            ctx.decode_meter_packets(d_pk, None, codec, C_, F_, stride, 20, d_st, info=d_info)
+            ctx.window_update(d_st, C_, F_, 160, win, info=d_info)
+        torch.cuda.synchronize()
+        outs.append((d_st, d_info, d_hold, d_probe))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert gu.to_host(outs[0][3], capi.CHAN_PROBE)["alarms"].sum() > probe0["alarms"].sum()
+    # round trip over the payload part of the same bytes (160-byte frames: reuse the buffer's head)
+    n = 160
+    pay = d_pk[: F_ * C_ * n]
+    rt = []
+    for blk in ("1", "0"):
+        monkeypatch.setenv("IGDSP_RT_BLK", blk)
+        d_out, d_st, d_hold = gu.dev_zeros(F_ * C_ * n, 0xEE), gu.dev_zeros(F_ * C_ * 16, 0xEE), gu.to_dev(hold0)
+        ctx.roundtrip_peakhold(pay, codec, C_, F_, n, d_out, d_st, d_hold, variant=capi.ENC_G191)
+        torch.cuda.synchronize()
+        rt.append((d_out, d_st, d_hold))
+    for a, b in zip(rt[0], rt[1]):
+        assert torch.equal(a, b)
