@@ -135,7 +135,7 @@ def _cpu_model() -> str:
 def _block_form(channels, env):
     """The launchers' rule for the block-owned form of the round trip / the fused window (igdsp_k_codec.hip launch_roundtrip,
     igdsp_capi.hip igdsp_decode_meter_window): as many channel groups per block (<= 4) as still give every CU a block, taken when
-    the blocks fill whole rounds of the CUs to 85 %.  Only used to NAME the dominant kernel in the JSON line."""
+    the blocks fill whole rounds of the CUs to 85 % or (window: always; round trip: from 0.6 of a round) within one round.  Only used to NAME the dominant kernel in the JSON line."""
     import torch
     e = os.environ.get(env)
     if e is not None:
@@ -146,7 +146,9 @@ def _block_form(channels, env):
     gpb = next((g for g in (4, 2) if n_groups % g == 0 and n_groups // g >= cus), 1)
     blocks = n_groups // gpb
     rounds = (blocks + cus - 1) // cus
-    return blocks * 100 >= rounds * cus * 85
+    if blocks * 100 >= rounds * cus * 85:
+        return True
+    return rounds == 1 and (env == "IGDSP_WIN_BLK" or blocks * 10 >= cus * 6)
 
 
 def main():

@@ -750,8 +750,8 @@ int igdsp_decode_meter_window(igdsp_ctx *ctx, uint32_t layout, const uint8_t *d_
         // Block-owned form (the default where it fits): a block owns gpb = 4, 2 or 1 consecutive channel groups for the launch,
         // hands their items to its waves in (frame, group) order and keeps their windows and runs in its LDS — the item-level
         // balance of the time-major kernels inside a block, no summaries, no finish kernel.  gpb: as many groups per block as
-        // still give every CU a block; taken when the blocks fill whole rounds of the CUs to 85 % (a launch of 1.25 rounds would
-        // idle 3/8 of the chip in its second round: the register form above has no such steps).  The packed LDS counters hold
+        // still give every CU a block; taken up to one round of blocks and when the blocks fill whole rounds of the CUs to 85 % (a launch
+        // of 1.25 rounds would idle 3/8 of the chip in its second round: the register form above has no such steps).  The packed LDS counters hold
         // 255 frames: longer launches go out as equal parts on the stream (hold / probe / the aggregate carry across them).
         {
             const uint32_t cus = (uint32_t)std::max(1, ctx->cus);
@@ -759,7 +759,10 @@ int igdsp_decode_meter_window(igdsp_ctx *ctx, uint32_t layout, const uint8_t *d_
             for (uint32_t g = 4u; g > 1u; g >>= 1) if (w.n_groups % g == 0u && w.n_groups / g >= cus) { gpb = g; break; }
             if (const char *e = std::getenv("IGDSP_WIN_GPB")) { const uint32_t g = (uint32_t)std::atoi(e); if ((g == 1u || g == 2u || g == 4u) && w.n_groups % g == 0u) gpb = g; }   // tests
             const uint32_t blocks = w.n_groups / gpb, rounds = (blocks + cus - 1u) / cus;
-            bool blk = (uint64_t)blocks * 100u >= (uint64_t)rounds * cus * 85u;
+            // (measured around the tuned 65 536 channels, register form / block form ms: 2 048 ch 0.0992 / 0.0658, 8 192 ch 0.1014 / 0.0685, 12 288 ch
+            // 0.1021 / 0.0705 — up to one round of blocks the block form always wins, the register form walks its segments serially — 24 576 ch
+            // 0.1218 / 0.1397, 49 152 ch 0.2332 / 0.2559: 1.5 rounds idle half the chip in the second)
+            bool blk = rounds == 1u || (uint64_t)blocks * 100u >= (uint64_t)rounds * cus * 85u;
             if (const char *e = std::getenv("IGDSP_WIN_BLK")) blk = std::atoi(e) != 0;       // experiments and tests: 0 = never, 1 = always
             if (blk) {
                 w.gpb = gpb; w.gsh = gpb == 4u ? 2u : (gpb == 2u ? 1u : 0u);

@@ -1440,6 +1440,15 @@ static uint32_t rtb_waves(uint32_t n, int max_waves, uint32_t gpb)
     return std::max(std::max(gpb, 1u), std::min(w, (uint32_t)max_waves));                         // (a wave per owned group folds it at the block's end)
 }
 
+// Where the block-owned form pays (65 536 channels = 256 blocks of four groups is the tuned case; measured around it, 128 frames,
+// placed buffers, static / block-owned ms): 0.6 to 1 round of blocks — 10 240 ch 0.0863 / 0.0841, 12 288 ch 0.1108 / 0.0856 — and whole
+// rounds filled to 85 %; below 0.6 of a round the static form spreads its units over more CUs (8 192 ch 0.0754 / 0.0804, 4 096 ch
+// 0.0649 / 0.0769), and 1.5 rounds idle half the chip in the second (24 576 ch 0.2003 / 0.2099, 49 152 ch 0.3572 / 0.3769).
+static bool rtb_fills(uint32_t blocks, uint32_t rounds, uint32_t cus)
+{
+    return (uint64_t)blocks * 100u >= (uint64_t)rounds * cus * 85u || (rounds == 1u && blocks * 10u >= cus * 6u);
+}
+
 hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F,
                             uint32_t n, uint8_t *out, igdsp_frame_stats *stats, igdsp_chan_hold *hold,
                             const uint8_t *gate, int variant, hipStream_t s)
@@ -1475,7 +1484,7 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
         for (uint32_t g = 4u; g > 1u; g >>= 1) if (n_groups_s % g == 0u && n_groups_s / g >= cus) { gpb = g; break; }
         if (const char *e = std::getenv("IGDSP_RT_GPB")) { const uint32_t g = (uint32_t)std::atoi(e); if ((g == 1u || g == 2u || g == 4u) && n_groups_s % g == 0u) gpb = g; }   // tests
         const uint32_t blocks = n_groups_s / gpb, rounds = (blocks + cus - 1u) / cus;
-        bool blk = F <= 65535u && (uint64_t)blocks * 100u >= (uint64_t)rounds * cus * 85u;
+        bool blk = F <= 65535u && rtb_fills(blocks, rounds, cus);
         if (const char *e = std::getenv("IGDSP_RT_BLK")) blk = F <= 65535u && std::atoi(e) != 0;       // experiments and tests
         if (blk) {
             const uint32_t gsh = gpb == 4u ? 2u : (gpb == 2u ? 1u : 0u);
@@ -1517,14 +1526,14 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
         n_seg = std::max(1u, std::min(n_seg, std::max(1u, F / 8u)));
         n_seg = std::max(n_seg, F / 65535u + 1u);               // the fused kernels count silent / clipped frames of a segment in 16 bits
         const uint32_t grid = blocks_for((uint64_t)n_groups * n_seg, waves, (uint32_t)cfg.compute_units);
-        // block-owned form: gpb = as many groups per block (<= 4: the LDS) as still give every CU a block; taken when its blocks fill
-        // whole rounds of the CUs to 85 % and F fits the 16-bit silent / clipped counts
+        // block-owned form: gpb = as many groups per block (<= 4: the LDS) as still give every CU a block; taken where rtb_fills says
+        // it pays and F fits the 16-bit silent / clipped counts
         uint32_t gpb = 1u;
         const uint32_t cus = (uint32_t)std::max(1, cfg.compute_units);
         for (uint32_t g = 4u; g > 1u; g >>= 1) if (n_groups % g == 0u && n_groups / g >= cus) { gpb = g; break; }
         if (const char *e = std::getenv("IGDSP_RT_GPB")) { const uint32_t g = (uint32_t)std::atoi(e); if ((g == 1u || g == 2u || g == 4u) && n_groups % g == 0u) gpb = g; }   // tests
         const uint32_t blocks = n_groups / gpb, rounds = (blocks + cus - 1u) / cus;
-        bool blk = kernel_variant != 4 && F <= 65535u && (uint64_t)blocks * 100u >= (uint64_t)rounds * cus * 85u;
+        bool blk = kernel_variant != 4 && F <= 65535u && rtb_fills(blocks, rounds, cus);
         if (const char *e = std::getenv("IGDSP_RT_BLK")) blk = kernel_variant != 4 && F <= 65535u && std::atoi(e) != 0;   // experiments and tests
         if (blk) {
             const uint32_t gsh = gpb == 4u ? 2u : (gpb == 2u ? 1u : 0u);
