@@ -146,9 +146,9 @@ def _block_form(channels, env):
     gpb = next((g for g in (4, 2) if n_groups % g == 0 and n_groups // g >= cus), 1)
     blocks = n_groups // gpb
     rounds = (blocks + cus - 1) // cus
-    if blocks * 100 >= rounds * cus * 85:
-        return True
-    return rounds == 1 and (env == "IGDSP_WIN_BLK" or blocks * 10 >= cus * 6)
+    if env == "IGDSP_WIN_BLK":
+        return rounds == 1 or blocks * 100 >= rounds * cus * 85
+    return rounds == 1 and blocks * 10 >= cus * 6
 
 
 def main():

@@ -1441,12 +1441,13 @@ static uint32_t rtb_waves(uint32_t n, int max_waves, uint32_t gpb)
 }
 
 // Where the block-owned form pays (65 536 channels = 256 blocks of four groups is the tuned case; measured around it, 128 frames,
-// placed buffers, static / block-owned ms): 0.6 to 1 round of blocks — 10 240 ch 0.0863 / 0.0841, 12 288 ch 0.1108 / 0.0856 — and whole
-// rounds filled to 85 %; below 0.6 of a round the static form spreads its units over more CUs (8 192 ch 0.0754 / 0.0804, 4 096 ch
-// 0.0649 / 0.0769), and 1.5 rounds idle half the chip in the second (24 576 ch 0.2003 / 0.2099, 49 152 ch 0.3572 / 0.3769).
+// placed buffers, static / block-owned ms): 0.6 to 1 round of blocks — 10 240 ch 0.0863 / 0.0841, 12 288 ch 0.1108 / 0.0856.  Below 0.6 of a
+// round the static form spreads its units over more CUs (8 192 ch 0.0754 / 0.0804, 4 096 ch 0.0649 / 0.0769); 1.5 rounds idle half the chip
+// in the second (24 576 ch 0.2003 / 0.2099, 49 152 ch 0.3572 / 0.3769), and even two whole rounds lose to the static form, whose blocks
+// stay (131 072 ch 0.9216 / 0.9311).
 static bool rtb_fills(uint32_t blocks, uint32_t rounds, uint32_t cus)
 {
-    return (uint64_t)blocks * 100u >= (uint64_t)rounds * cus * 85u || (rounds == 1u && blocks * 10u >= cus * 6u);
+    return rounds == 1u && blocks * 10u >= cus * 6u;
 }
 
 hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F,
