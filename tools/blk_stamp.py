@@ -46,9 +46,6 @@ for it in range(30, 40):
     a, b, c, x = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0, t[:, 3] & 15
     print("start us: max %.1f | items done us: min %.1f mean %.1f p90 %.1f max %.1f | fold us: mean %.2f max %.2f | all done max %.1f" %
           (a.max(), b.min(), b.mean(), np.percentile(b, 90), b.max(), (c - b).mean(), (c - b).max(), c.max()))
-    print("   fold phases (us after items done): masks in LDS %.2f, segments scanned %.2f, stored %.2f" % (((t[:, 3] >> 8) & 0xFFF).mean() / 100.0, ((t[:, 3] >> 20) & 0xFFF).mean() / 100.0, (c - b).mean()))
-    t2 = work[C_ // 64 * F_ + G: C_ // 64 * F_ + 2 * G].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
-    print("   scan loop starts %.2f ends %.2f" % (t2[:, 0].mean() / 100.0, t2[:, 1].mean() / 100.0))
     if it == 39:
         for xc in range(8):
             m = x == xc
