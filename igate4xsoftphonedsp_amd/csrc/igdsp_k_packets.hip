@@ -137,6 +137,61 @@ __device__ __forceinline__ void win_drain(uint32_t *commit, const uint32_t *flag
     }
 }
 
+// WIN == 2, one folded frame of one channel (this lane): the window's LDS atomics and the run's in-order commit.
+__device__ __forceinline__ void win_blk_item(const WinArgs &win, uint32_t id_cur, uint32_t lane, uint32_t l, bool metered, uint32_t ed, uint64_t sumsq16,
+                                             uint32_t peak, uint32_t bm, uint32_t fl, uint32_t c_seen, uint32_t c_run, uint32_t c_al,
+                                             uint32_t *wst, uint32_t *w_commit, uint32_t *w_flag, uint4 *w_ring, uint32_t *w_run, uint32_t *w_alarms)
+{
+    const uint32_t gj = id_cur & (win.gpb - 1u), cl = gj * 64u + lane;          // this lane's channel within the block
+    const bool fold = metered && (win.gate_mask == 0u || (ed & win.gate_mask) != 0u);
+    if (fold) {                               // integer sums / max / min: any order
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(wst) + cl, (unsigned long long)sumsq16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(wst + 2 * kWinBlkCh + cl, 1u | ((fl & IGDSP_FLAG_SILENT) ? 0x100u : 0u) | ((fl & IGDSP_FLAG_CLIPPED) ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(wst + 3 * kWinBlkCh + cl, bm | (l << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(wst + 4 * kWinBlkCh + cl, peak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(wst + 5 * kWinBlkCh + cl, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_min(wst + 6 * kWinBlkCh + cl, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#ifdef IGDSP_BLK_NORUN            // A/B builds only (wrong runs on purpose): what the commit protocol costs
+    if (win.probe != nullptr && l == 77777u) {
+#else
+    if (win.probe != nullptr) {
+#endif
+        // The run moves in FRAME order and the frames of a group are folded by different waves in any order.  Nobody
+        // waits (a first version made every frame wait for its predecessor: +3 %), and the common case has no
+        // LDS round trip in the wave's way (with two the launch was 3 % slower: an item's time is its loads' latency).
+        // w_commit[j] = the next frame of group j to commit, bit 31 = a wave is committing.  The compare-and-swap
+        // issued at the top of the fold takes the group if this frame IS the next one: the frame is applied from
+        // registers and the group released, nothing read back.  Any other wave leaves its frame's probe / reset masks
+        // in the group's ring and then looks at the group: if it is free and its next frame is there it takes the group
+        // and applies every consecutive frame it finds.  Frames left while a wave held the group stay until a later
+        // frame finds the group free — that frame cannot be the group's next one, so it comes this way; what is left
+        // when the block's items are through is applied at the block's end.
+        const bool valid = metered && l > 48u, pr = valid && (fl & IGDSP_FLAG_PROBE_D5) != 0u, npr = valid && !pr;
+        const uint32_t fr_no = id_cur >> win.gsh, kLock = 0x80000000u;
+        uint32_t run = c_run, al = c_al;
+        uint32_t seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)c_seen);
+        if (seen == fr_no) {                 // this frame was next and the group free
+            win_step(run, al, pr, npr, win.alarm);
+            w_run[cl] = run; w_alarms[cl] = al;
+            if (lane == 0u) __hip_atomic_store(&w_commit[gj], fr_no + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            while ((seen & ~kLock) + (uint32_t)kWinRing <= fr_no) {     // (the slot's previous frame, 16 back: never pending in practice)
+                __builtin_amdgcn_s_sleep(1);
+                win_drain(w_commit, w_flag, w_ring, w_run, w_alarms, gj, lane, win.alarm);
+                seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&w_commit[gj], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+            }
+            const uint64_t mp = __ballot(pr), mn = __ballot(npr);
+            if (lane == 0u) {
+                const uint32_t sl = gj * (uint32_t)kWinRing + (fr_no & (uint32_t)(kWinRing - 1));
+                w_ring[sl] = make_uint4((uint32_t)mp, (uint32_t)mn, (uint32_t)(mp >> 32), (uint32_t)(mn >> 32));
+                __hip_atomic_store(&w_flag[sl], fr_no + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            win_drain(w_commit, w_flag, w_ring, w_run, w_alarms, gj, lane, win.alarm);     // (skipped when the group was seen held: +0.7 %, the rings fill)
+        }
+    }
+}
+
 // MIXED (packed form only): the header length is per channel, 20 bytes where radio[c] != 0 and 12 elsewhere (SIP and
 // ED-137 legs in one launch, as in the reference's process); `hdr` is then ignored.  The radio flags travel like the
 // codec ids: the frame lanes fetch them one item ahead and a ballot hands every piece its packet's bit.
@@ -425,55 +480,8 @@ __global__ __launch_bounds__(kRtpWaves * 64) void k_meter_rtp64(
                     u_clip += (uint32_t)__builtin_popcountll(__ballot(metered && (fl & IGDSP_FLAG_CLIPPED) != 0u));
                 }
                 if (WIN == 2) {
-                    const uint32_t l = whole ? (uint32_t)kFrame : plen;
-                    const uint32_t gj = id_cur & (win.gpb - 1u), cl = gj * 64u + lane;          // this lane's channel within the block
-                    const bool fold = metered && (win.gate_mask == 0u || (ed & win.gate_mask) != 0u);
-                    if (fold) {                               // integer sums / max / min: any order
-                        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(wst) + cl, (unsigned long long)(s << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(wst + 2 * kWinBlkCh + cl, 1u | ((fl & IGDSP_FLAG_SILENT) ? 0x100u : 0u) | ((fl & IGDSP_FLAG_CLIPPED) ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(wst + 3 * kWinBlkCh + cl, bm | (l << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_max(wst + 4 * kWinBlkCh + cl, peak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_max(wst + 5 * kWinBlkCh + cl, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_min(wst + 6 * kWinBlkCh + cl, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-#ifdef IGDSP_BLK_NORUN            // A/B builds only (wrong runs on purpose): what the commit protocol costs
-                    if (win.probe != nullptr && l == 77777u) {
-#else
-                    if (win.probe != nullptr) {
-#endif
-                        // The run moves in FRAME order and the frames of a group are folded by different waves in any order.  Nobody
-                        // waits (a first version made every frame wait for its predecessor: +3 %), and the common case has no
-                        // LDS round trip in the wave's way (with two the launch was 3 % slower: an item's time is its loads' latency).
-                        // w_commit[j] = the next frame of group j to commit, bit 31 = a wave is committing.  The compare-and-swap
-                        // issued at the top of the fold takes the group if this frame IS the next one: the frame is applied from
-                        // registers and the group released, nothing read back.  Any other wave leaves its frame's probe / reset masks
-                        // in the group's ring and then looks at the group: if it is free and its next frame is there it takes the group
-                        // and applies every consecutive frame it finds.  Frames left while a wave held the group stay until a later
-                        // frame finds the group free — that frame cannot be the group's next one, so it comes this way; what is left
-                        // when the block's items are through is applied at the block's end.
-                        const bool valid = metered && l > 48u, pr = valid && (fl & IGDSP_FLAG_PROBE_D5) != 0u, npr = valid && !pr;
-                        const uint32_t fr_no = id_cur >> win.gsh, kLock = 0x80000000u;
-                        uint32_t run = c_run, al = c_al;
-                        uint32_t seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)c_seen);
-                        if (seen == fr_no) {                 // this frame was next and the group free
-                            win_step(run, al, pr, npr, win.alarm);
-                            w_run[cl] = run; w_alarms[cl] = al;
-                            if (lane == 0u) __hip_atomic_store(&w_commit[gj], fr_no + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        } else {
-                            while ((seen & ~kLock) + (uint32_t)kWinRing <= fr_no) {     // (the slot's previous frame, 16 back: never pending in practice)
-                                __builtin_amdgcn_s_sleep(1);
-                                win_drain(w_commit, w_flag, w_ring, w_run, w_alarms, gj, lane, win.alarm);
-                                seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&w_commit[gj], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-                            }
-                            const uint64_t mp = __ballot(pr), mn = __ballot(npr);
-                            if (lane == 0u) {
-                                const uint32_t sl = gj * (uint32_t)kWinRing + (fr_no & (uint32_t)(kWinRing - 1));
-                                w_ring[sl] = make_uint4((uint32_t)mp, (uint32_t)mn, (uint32_t)(mp >> 32), (uint32_t)(mn >> 32));
-                                __hip_atomic_store(&w_flag[sl], fr_no + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            }
-                            win_drain(w_commit, w_flag, w_ring, w_run, w_alarms, gj, lane, win.alarm);     // (skipped when the group was seen held: +0.7 %, the rings fill)
-                        }
-                    }
+                    win_blk_item(win, id_cur, lane, whole ? (uint32_t)kFrame : plen, metered, ed, s << 4, peak, bm, fl, c_seen, c_run, c_al,
+                                 wst, w_commit, w_flag, w_ring, w_run, w_alarms);
                 } else if (WIN) {
 #ifndef IGDSP_WIN_NOBOOK          // A/B builds only: the walk without the per-frame bookkeeping (wrong windows on purpose)
                     // branch-free: every step is a select on the lane's own predicates
