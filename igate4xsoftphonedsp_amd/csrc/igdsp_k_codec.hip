@@ -845,12 +845,12 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 // launch, hands their F * gpb items to its waves one at a time, keeps the windows in LDS (integer atomics) and folds them into
 // hold[c] itself; odd blocks walk the frames from the middle of the launch.  n_seg carries gpb and order log2(gpb) then.
 template <int Q, bool TAIL, int VARIANT, bool BLK = false>
-__global__ __launch_bounds__((BLK ? kRtsbWaves : kRtlWaves) * 64) void k_roundtrip_strided(
+__global__ __launch_bounds__((BLK ? (Q <= 1 ? 16 : kRtsbWaves) : kRtlWaves) * 64) void k_roundtrip_strided(
     const uint8_t *__restrict__ payload, const uint8_t *__restrict__ codec, uint32_t C, uint32_t F, uint32_t n,
     uint8_t *__restrict__ out, igdsp_frame_stats *__restrict__ stats, igdsp_chan_hold *__restrict__ hold,
     const uint8_t *__restrict__ gate, uint32_t n_seg, uint32_t n_groups, uint32_t order)
 {
-    constexpr int kW = BLK ? kRtsbWaves : kRtlWaves;
+    constexpr int kW = BLK ? (Q <= 1 ? 16 : kRtsbWaves) : kRtlWaves;      // (16 .. 28-byte frames: small strips, 1.5 KiB items — as many waves as a block takes)
     static_assert(Q == 1 || Q >= 4, "the probe bytes 28 / 38 / 48 are taken from pieces 1 / 2 / 3");
     constexpr int QP = Q + (TAIL ? 1 : 0);
     constexpr int kStrip = kSuperFrames * QP;
@@ -1435,7 +1435,7 @@ static uint32_t rtb_waves(uint32_t n, int max_waves, uint32_t gpb)
 {
     // about 60 KB of loads in flight per CU: 6 waves at 160 bytes per frame, 4 at 240, 10 (the strips' limit) at 80 and below; the tailed
     // sizes want two more (164 bytes: 4 / 6 / 8 / 10 waves 0.6413 / 0.5146 / 0.4854 / 0.4915 ms; 240: 0.6636 / 0.6740 / 0.6746 / 0.6804)
-    uint32_t w = n >= 200u ? 4u : (n > 160u ? 8u : (n >= 120u ? 6u : 10u));
+    uint32_t w = n >= 200u ? 4u : (n > 160u ? 8u : (n >= 120u ? 6u : (n >= 48u ? 10u : 16u)));
     if (const char *e = std::getenv("IGDSP_RTB_WAVES")) w = (uint32_t)std::max(1, std::atoi(e));   // experiments
     return std::max(std::max(gpb, 1u), std::min(w, (uint32_t)max_waves));                         // (a wave per owned group folds it at the block's end)
 }
@@ -1489,7 +1489,7 @@ hipError_t launch_roundtrip(const LaunchCfg &cfg, int kernel_variant, const uint
         if (const char *e = std::getenv("IGDSP_RT_BLK")) blk = F <= 65535u && std::atoi(e) != 0;       // experiments and tests
         if (blk) {
             const uint32_t gsh = gpb == 4u ? 2u : (gpb == 2u ? 1u : 0u);
-            const dim3 gb(blocks), bb(rtb_waves(n, kRtsbWaves, gpb) * 64u);
+            const dim3 gb(blocks), bb(rtb_waves(n, Qn <= 1u ? 16 : kRtsbWaves, gpb) * 64u);
 #define IGDSP_RTSB(QV, TV)                                                                                                                                     \
             if (Qn == QV && (Tn != 0u) == TV) {                                                                                                                 \
                 if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_roundtrip_strided<QV, TV, IGDSP_ENC_G191, true>), gb, bb, 0, s, payload, codec, C, F, n, out, stats, hold, gate, gpb, n_groups_s, gsh | (mid_start << 2));  \
