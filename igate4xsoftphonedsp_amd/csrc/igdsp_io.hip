@@ -665,7 +665,9 @@ int igdsp_io_alloc(igdsp_ctx *ctx, igdsp_io_buf *bufs, uint32_t n_bufs, size_t e
                     const size_t want_b = need_b + (cc.size() < need_c ? need_c - cc.size() : 0);   // B also serves what C could not
                     if (ok && cb.size() < want_b) walk(from, want_b, is_B, cb);
                     if (X.debug) std::fprintf(stderr, "[igdsp_io] split: class B %zu of %zu chunks, class C %zu of %zu\n", cb.size(), need_b, cc.size(), need_c);
-                    if (ok && cc.size() >= std::max<size_t>(4, need_c / 2)) {
+                    // (enough of class C: everything the second halves need, or at least four chunks and half of it.  Requiring four chunks
+                    // outright turned down small sets whose two or three C chunks had all been found — 80-byte frames, C 160 GB into the sequence.)
+                    if (ok && (cc.size() >= need_c || cc.size() >= std::max<size_t>(4, need_c / 2))) {
                         R.classes_found = 3;
                         poolB = cb;
                         poolC = cc;
