@@ -25,7 +25,7 @@ def main():
     for _ in range(200):
         fn(ctx.h, p_in, p_out, p_out + win, n_items, 8, 8, 16, None, None)
     for r, w in [(8, 8), (8, 4), (4, 8), (10, 1), (8, 2)]:
-        for waves in (8, 12, 16):
+        for waves in (3, 4, 6, 8, 12, 16):
             res = []
             for d2 in (p_out, p_out + win):           # all writes into the first half (one class) | odd items into the second half (two classes)
                 for _ in range(5):
