@@ -215,7 +215,7 @@ int igdsp_destroy(igdsp_ctx *ctx)
     void *hosts[] = {ctx->h_ring, ctx->h_rlen, ctx->h_rpt, ctx->h_red, ctx->h_up, ctx->pub[0].last, ctx->pub[0].hold, ctx->pub[0].probe,
                      ctx->pub[1].last, ctx->pub[1].hold, ctx->pub[1].probe};
     for (void *p : hosts) if (p) (void)hipHostFree(p);
-    void *devs[] = {ctx->d_up, ctx->d_stats, ctx->d_last, ctx->d_hold, ctx->d_probe, ctx->d_queues};
+    void *devs[] = {ctx->d_up, ctx->d_stats, ctx->d_last, ctx->d_hold, ctx->d_probe, ctx->d_queues, ctx->d_enc_tab[0], ctx->d_enc_tab[1]};
     for (void *p : devs) if (p) (void)hipFree(p);
     delete ctx;
     return IGDSP_OK;
@@ -551,7 +551,21 @@ int igdsp_encode(igdsp_ctx *ctx, const int16_t *d_pcm, const uint8_t *d_codec, u
     if (variant != IGDSP_ENC_SUN16 && variant != IGDSP_ENC_G191) return IGDSP_EINVAL;
     if (int rc = check_shape(C, F, n)) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_encode(cfg_of(ctx, pick(ctx, stream)), d_pcm, d_codec, C, F, n, d_out, variant, pick(ctx, stream)));
+    igdsp::LaunchCfg cfg = cfg_of(ctx, pick(ctx, stream));
+    if ((uint64_t)C * F * n >= (1ull << 25)) {                     // the batches k_encode_lut16 serves: its table, built once per context and lineage
+        const int v = variant == IGDSP_ENC_G191 ? 1 : 0;
+        std::call_once(ctx->enc_once[v], [&]() {
+            uint8_t *t = nullptr;
+            hipStream_t bs = nullptr;
+            bool ok = hipMalloc((void **)&t, 2u * 65536u) == hipSuccess && hipStreamCreateWithFlags(&bs, hipStreamNonBlocking) == hipSuccess;
+            ok = ok && igdsp::launch_build_enc_table(variant, t, bs) == hipSuccess && hipStreamSynchronize(bs) == hipSuccess;
+            if (bs) (void)hipStreamDestroy(bs);
+            if (ok) ctx->d_enc_tab[v] = t;                          // complete before any launch that reads it is enqueued
+            else { if (t) (void)hipFree(t); (void)hipGetLastError(); }   // the kernel evaluates the table itself, as before
+        });
+        cfg.enc_tab = ctx->d_enc_tab[v];
+    }
+    HIP_TRY(ctx, launch_encode(cfg, d_pcm, d_codec, C, F, n, d_out, variant, pick(ctx, stream)));
     return IGDSP_OK;
 }
 

@@ -100,6 +100,11 @@ struct igdsp_ctx {
     // igdsp_sync(ctx, stream) has seen it idle; when all pairs are taken a launch on a new stream runs the static per-block
     // schedule (gqueue = nullptr: same results, ~2.5 % slower on the headline shape).
     uint32_t *d_queues = nullptr;                       // kQueueRing x 32 words (pair i at word 32 i: 128 B apart)
+    // igdsp_encode's full 16-bit compressor table (2 laws x 65 536 codes) per encoder lineage, built once on the device by the
+    // arithmetic every kernel shares (enc_uni) the first time a large batch asks for it; k_encode_lut16 then COPIES its 128 KiB
+    // of LDS instead of evaluating 131 072 inputs per block and launch.  nullptr: not built (the kernel evaluates, as before).
+    uint8_t *d_enc_tab[2] = {nullptr, nullptr};
+    std::once_flag enc_once[2];
     hipStream_t queue_owner[64];                        // stream that owns pair i, or kFreeQueue (meaningful for i < queue_used)
     uint32_t queue_launches[64];                        // launches handed pair i since it was taken (igdsp_sync's idle check)
     uint32_t queue_used = 0;

@@ -23,6 +23,7 @@ struct LaunchCfg {
     uint32_t *gqueue;    // device-wide work counter {next batch, blocks done} for this launch, zero on entry
                          // and re-armed by the kernel itself; nullptr = static per-block distribution
     bool out_spread = false;   // the launch's bulk output sits half in one, half in another memory class (igdsp_io_alloc)
+    const uint8_t *enc_tab = nullptr;   // igdsp_encode: the context's ready-made compressor table of this lineage (2 x 65 536 bytes), or nullptr
 };
 
 // The ED-137 gated window of a fused packet launch (igdsp_decode_meter_window): work = uint4[n_seg][3][C] unit summaries (window
@@ -59,6 +60,7 @@ hipError_t launch_window_finish(const uint4 *work, uint32_t C, uint32_t n_seg, u
                                 igdsp_chan_probe *probe, hipStream_t s);
 hipError_t launch_diag_chunk32(const LaunchCfg &cfg, const uint8_t *payload, const uint8_t *codec, uint32_t C, uint32_t F,
                                igdsp_frame_stats *stats, uint64_t *diag, hipStream_t s);
+hipError_t launch_build_enc_table(int variant, uint8_t *tab, hipStream_t s);   // tab[law << 16 | uint16(v)] = enc(v), 131 072 bytes
 hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t *codec,
                          uint32_t C, uint32_t F, uint32_t n, uint8_t *out, int variant, hipStream_t s);
 hipError_t launch_encode_table(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t *codec, uint32_t C, uint32_t F, uint32_t n,

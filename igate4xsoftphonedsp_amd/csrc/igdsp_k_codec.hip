@@ -195,14 +195,17 @@ constexpr int kEncWaves = IGDSP_ENC_WAVES;
 template <int VARIANT>
 __global__ __launch_bounds__(kEncWaves * 64) void k_encode_lut16(const int16_t *__restrict__ pcm, const uint8_t *__restrict__ codec,
                                                        uint32_t C, uint32_t n, uint32_t n_groups, uint8_t *__restrict__ out,
-                                                       uint32_t *gqueue)
+                                                       uint32_t *gqueue, const uint8_t *__restrict__ tab_g)
 {
     constexpr int kW = kEncWaves;
-    __shared__ uint8_t tab[2 * 65536];
+    __shared__ __attribute__((aligned(16))) uint8_t tab[2 * 65536];
     __shared__ BlockQueue<kW> bq;
     uint32_t gb1 = 0;
     if (threadIdx.x == 0 && gqueue != nullptr) gb1 = atomicAdd(gqueue, 1u);
-    {
+    if (tab_g != nullptr) {                                       // the context's ready-made table (k_build_enc_table): 128 KiB out of L2
+        for (uint32_t i = threadIdx.x * 16u; i < 2u * 65536u; i += blockDim.x * 16u)
+            *reinterpret_cast<uint4 *>(tab + i) = *reinterpret_cast<const uint4 *>(tab_g + i);
+    } else {
         const EncK ku = enc_consts<VARIANT>(false), ka = enc_consts<VARIANT>(true);
         for (uint32_t i = threadIdx.x; i < 2u * 65536u; i += blockDim.x)
             tab[i] = (uint8_t)enc_uni<VARIANT>((int)(int16_t)(i & 0xFFFFu), (i >> 16) ? ka : ku);
@@ -1386,6 +1389,22 @@ __global__ __launch_bounds__(256) void k_window_finish(const uint4 *__restrict__
     if (probe) probe[c] = p;
 }
 
+// The table k_encode_lut16 keeps in LDS, evaluated once per context and lineage: tab[law << 16 | uint16(v)] = enc_uni(v).
+template <int VARIANT>
+__global__ __launch_bounds__(1024) void k_build_enc_table(uint8_t *__restrict__ tab)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2u * 65536u) return;
+    tab[i] = (uint8_t)enc_uni<VARIANT>((int)(int16_t)(i & 0xFFFFu), enc_consts<VARIANT>((i >> 16) != 0u));
+}
+
+hipError_t launch_build_enc_table(int variant, uint8_t *tab, hipStream_t s)
+{
+    if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_build_enc_table<IGDSP_ENC_G191>), dim3(128), dim3(1024), 0, s, tab);
+    else                           hipLaunchKernelGGL((k_build_enc_table<IGDSP_ENC_SUN16>), dim3(128), dim3(1024), 0, s, tab);
+    return hipGetLastError();
+}
+
 hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t *codec, uint32_t C, uint32_t F,
                          uint32_t n, uint8_t *out, int variant, hipStream_t s)
 {
@@ -1397,8 +1416,8 @@ hipError_t launch_encode(const LaunchCfg &cfg, const int16_t *pcm, const uint8_t
     if (v8 && n_samples >= (1u << 25) && (n_samples >> 3) < 0xFFFF0000ull) {   // large batches: full 16-bit table, one block per CU (32-bit group ids)
         const uint32_t groups = (uint32_t)(n_samples >> 3);    // 32-bit group ids (checked above)
         const uint32_t grid = blocks_for(groups, 1024, (uint32_t)cfg.compute_units);
-        if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_G191>), dim3(grid), dim3(kEncWaves * 64), 0, s, pcm, codec, C, n, groups, out, cfg.gqueue);
-        else                           hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_SUN16>), dim3(grid), dim3(kEncWaves * 64), 0, s, pcm, codec, C, n, groups, out, cfg.gqueue);
+        if (variant == IGDSP_ENC_G191) hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_G191>), dim3(grid), dim3(kEncWaves * 64), 0, s, pcm, codec, C, n, groups, out, cfg.gqueue, cfg.enc_tab);
+        else                           hipLaunchKernelGGL((k_encode_lut16<IGDSP_ENC_SUN16>), dim3(grid), dim3(kEncWaves * 64), 0, s, pcm, codec, C, n, groups, out, cfg.gqueue, cfg.enc_tab);
     } else if (v8 && n_samples >= (1u << 22)) {                 // big batches: table-driven compressor, persistent blocks
         const uint64_t groups = n_samples >> 3;
         const uint32_t grid = blocks_for(groups, 1024, (uint32_t)cfg.compute_units * 2u);
