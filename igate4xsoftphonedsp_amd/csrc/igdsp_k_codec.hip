@@ -518,18 +518,23 @@ __global__ __launch_bounds__(kRtWaves * 64) void k_roundtrip_chunk64(
 #endif
 constexpr int kRtlWaves = IGDSP_RTL_WAVES;
 
+// Every one of the 256 entries is evaluated ONCE per block (two compressor evaluations each) into its replica 0 and copied to the
+// other 31 replicas from there: with the few waves the block-owned round trip runs (6 x 64 threads) evaluating all 8 192 slots took
+// 43 pairs of enc_uni per thread and launch.  Contains a barrier: call it from all threads; the caller's own barrier follows.
 template <int VARIANT>
 __device__ __forceinline__ void fill_recode_lut(uint2 *lut)
 {
     const EncK ku = enc_consts<VARIANT>(false), ka = enc_consts<VARIANT>(true);
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kLutEntries; i += blockDim.x) {
-        const uint32_t e = i >> 5;                 // law<<7 | code7
+    for (uint32_t e = threadIdx.x; e < 256u; e += blockDim.x) {          // e = law<<7 | code7
         const bool alaw = (e & 0x80u) != 0u;
         const uint32_t ax = alaw ? alaw_abs(e) : ulaw_abs(e);
         const uint32_t m = ax >> 2;
         const uint32_t en = enc_uni<VARIANT>(-(int)ax, alaw ? ka : ku), ep = enc_uni<VARIANT>((int)ax, alaw ? ka : ku);
-        lut[i] = make_uint2(m * m, en | (ep << 8) | (ax << 16));
+        lut[e << 5] = make_uint2(m * m, en | (ep << 8) | (ax << 16));
     }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kLutEntries; i += blockDim.x)
+        if ((i & 31u) != 0u) lut[i] = lut[i & ~31u];
 }
 
 // Per-lane piece constants of a half, packed: five 5-bit frame indices (frame-in-half of piece j) in `fr5`, five 5-bit probe
