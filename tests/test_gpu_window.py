@@ -226,7 +226,7 @@ def test_fused_window_segment_counts(ctx, orc, monkeypatch, nseg):
     assert gu.to_host(d_probe, capi.CHAN_PROBE).tobytes() == ep.tobytes()
 
 
-@pytest.mark.parametrize("gpb,C_,F_,alarm", [("4", 1024, 50, 3), ("2", 384, 90, 500), ("1", 192, 300, 7), ("4", 256, 520, 2), ("2", 128, 255, 4)])
+@pytest.mark.parametrize("gpb,C_,F_,alarm", [("4", 1024, 50, 3), ("2", 384, 90, 500), ("1", 192, 300, 7), ("4", 256, 520, 2), ("2", 128, 255, 4), ("1", 64, 1, 1), ("4", 256, 256, 6)])
 def test_fused_window_block_form(ctx, orc, monkeypatch, gpb, C_, F_, alarm):
     """The block-owned form at 4 / 2 / 1 channel groups per block (the launcher's own rule only leaves one group per block at
     these sizes), launches longer than the 255 frames its packed LDS counters hold (300 -> 2 parts, 520 -> 3), runs that enter
@@ -264,7 +264,8 @@ def test_fused_window_block_form(ctx, orc, monkeypatch, gpb, C_, F_, alarm):
             assert np.array_equal(gh[fld], eh[fld]), (with_records, fld, np.argwhere(gh[fld] != eh[fld])[:4].tolist())
         for fld in capi.CHAN_PROBE.names:
             assert np.array_equal(gp[fld], ep[fld]), (with_records, fld, np.argwhere(gp[fld] != ep[fld])[:4].tolist())
-    assert ep["alarms"].sum() > probe0["alarms"].sum()
+    if F_ > 1:
+        assert ep["alarms"].sum() > probe0["alarms"].sum()
 
 
 @pytest.mark.parametrize("blk", ["0", "1"])
